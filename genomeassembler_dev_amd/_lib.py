@@ -1,0 +1,148 @@
+"""ctypes binding of libgasm.so (include/gasm.h).  There is no fallback: if the library is missing or no gfx950 GPU is
+usable, calls raise — the product never computes on the CPU."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgasm.so")
+
+GASM_OK = 0
+STATUS = {0: "GASM_OK", -1: "GASM_ERR_INVALID", -2: "GASM_ERR_NON_ACGT", -3: "GASM_ERR_NO_DEVICE", -4: "GASM_ERR_HIP",
+          -5: "GASM_ERR_CAPACITY", -6: "GASM_ERR_RANGE", -7: "GASM_ERR_STATE"}
+TABLE_ROWS = 69904
+SCORE_OWN, SCORE_VELVET = 0, 1
+WANT_LEV, WANT_FREQ = 1, 2
+
+
+class GasmError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"{STATUS.get(status, status)}: {text}")
+        self.status = status
+
+
+_vp, _u64, _u32, _i32, _int = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_int
+_PP = C.POINTER(C.c_void_p)
+
+# every symbol include/gasm.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "gasm_last_error": (C.c_char_p, []),
+    "gasm_version": (C.c_char_p, []),
+    "gasm_ctx_create": (_int, [_int, _PP]),
+    "gasm_ctx_destroy": (None, [_vp]),
+    "gasm_ctx_sync": (_int, [_vp]),
+    "gasm_ctx_stream": (_vp, [_vp]),
+    "gasm_get_contigs": (_int, [_vp, _vp, _u64, _int, _int, _int, _PP]),
+    "gasm_contigs_count": (_u64, [_vp]),
+    "gasm_contigs_data": (_vp, [_vp]),
+    "gasm_contigs_offsets": (_vp, [_vp]),
+    "gasm_contigs_rows": (_u64, [_vp]),
+    "gasm_contigs_perm": (_vp, [_vp]),
+    "gasm_contigs_distinct_count": (_u64, [_vp]),
+    "gasm_contigs_key_words": (_int, [_vp]),
+    "gasm_contigs_distinct_keys": (_vp, [_vp]),
+    "gasm_contigs_distinct_mult": (_vp, [_vp]),
+    "gasm_contigs_free": (None, [_vp]),
+    "gasm_assemble_contigs": (_int, [_vp, _vp, _vp, _u64, _vp, _u64, _u64, _int, _PP]),
+    "gasm_assemble_contigs_velvet": (_int, [_vp, _vp, _vp, _u64, _int, _int, _int, _PP]),
+    "gasm_strlist_count": (_u64, [_vp]),
+    "gasm_strlist_data": (_vp, [_vp]),
+    "gasm_strlist_offsets": (_vp, [_vp]),
+    "gasm_strlist_free": (None, [_vp]),
+    "gasm_calc_breakscore": (_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _u64, _vp, _int, _int,
+                                    _PP]),
+    "gasm_scores_count": (_u64, [_vp]),
+    "gasm_scores_sequence_len": (_vp, [_vp]),
+    "gasm_scores_bp_score": (_vp, [_vp]),
+    "gasm_scores_norm_by_break_freqs": (_vp, [_vp]),
+    "gasm_scores_norm_by_len": (_vp, [_vp]),
+    "gasm_scores_kmer_breaks": (_vp, [_vp]),
+    "gasm_scores_lev_dist": (_vp, [_vp]),
+    "gasm_scores_path_freq": (_vp, [_vp]),
+    "gasm_scores_startpos": (_vp, [_vp]),
+    "gasm_scores_prob_dist": (_vp, [_vp]),
+    "gasm_scores_prob_dist_offsets": (_vp, [_vp]),
+    "gasm_scores_free": (None, [_vp]),
+    "gasm_levenshtein": (_int, [_vp, _u64, _vp, _u64, _int, C.POINTER(_i32)]),
+    "gasm_batch_create": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _u32, _PP]),
+    "gasm_batch_free": (None, [_vp]),
+    "gasm_batch_build": (_int, [_vp, _int, _u64]),
+    "gasm_batch_score": (_int, [_vp, _int, _vp]),
+    "gasm_batch_total_kmers": (_u64, [_vp]),
+    "gasm_batch_total_reads": (_u64, [_vp]),
+    "gasm_batch_fetch_distinct": (_int, [_vp, _PP, _PP, _PP, C.POINTER(_int)]),
+    "gasm_batch_fetch_contigs": (_int, [_vp, _PP, _PP, _PP]),
+    "gasm_batch_fetch_scores": (_int, [_vp, _PP, _PP, _PP, _PP, _PP]),
+    "gasm_profile_enable": (_int, [_vp, _int]),
+    "gasm_profile_reset": (_int, [_vp]),
+    "gasm_profile_read": (_int, [_vp, C.POINTER(_int), _PP, _PP, _PP]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc, gfx950).  genomeassembler_dev_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != GASM_OK:
+        raise GasmError(status, (lib().gasm_last_error() or b"").decode(errors="replace"))
+
+
+_ctxs = {}
+
+
+class Context:
+    """One GPU, one HIP stream (gasm_ctx)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        check(lib().gasm_ctx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+
+    def sync(self):
+        check(lib().gasm_ctx_sync(self.h))
+
+    def stream(self):
+        return lib().gasm_ctx_stream(self.h)
+
+    def profile(self, on=True):
+        check(lib().gasm_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        check(lib().gasm_profile_reset(self.h))
+
+    def profile_read(self):
+        """{kernel name: (total ms, launches)} since the last reset"""
+        n = C.c_int()
+        names, ms, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib().gasm_profile_read(self.h, C.byref(n), C.byref(names), C.byref(ms), C.byref(cnt)))
+        if n.value == 0:
+            return {}
+        nm = C.cast(names, C.POINTER(C.c_char_p))
+        m = C.cast(ms, C.POINTER(C.c_double))
+        c = C.cast(cnt, C.POINTER(C.c_uint64))
+        return {nm[i].decode(): (m[i], int(c[i])) for i in range(n.value)}
+
+    def close(self):
+        if self.h:
+            lib().gasm_ctx_destroy(self.h)
+            self.h = None
+
+
+def default_context(device=0):
+    if device not in _ctxs:
+        _ctxs[device] = Context(device)
+    return _ctxs[device]

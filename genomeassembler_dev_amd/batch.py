@@ -1,0 +1,117 @@
+"""SegmentBatch: reads of many independent segments in, contigs + breakage scores out, everything resident in HBM
+between the calls (gasm_batch_* in include/gasm.h).  This is the reads-level surface the reference only has in R
+(lib/DeNovoAssembler.R:58-68: get_reads -> get_kmers_from_reads -> get_contigs -> calc_breakscore)."""
+import ctypes as C
+
+import numpy as np
+
+from . import qtable
+from ._lib import check, default_context, lib
+from .api import unpack_kmers
+
+
+class SegmentBatch:
+    def __init__(self, reads, seg_read_off, fixed_len=0, read_off=None, ctx=None):
+        """reads: uint8 array (ASCII ACGT) of all reads of all segments, concatenated segment after segment.
+        seg_read_off: n_segments+1 read indices.  Either fixed_len > 0 or read_off (n_reads+1 base offsets)."""
+        self.ctx = ctx or default_context()
+        reads = np.ascontiguousarray(reads, dtype=np.uint8)
+        seg = np.ascontiguousarray(seg_read_off, dtype=np.uint64)
+        self.n_segments = len(seg) - 1
+        self.n_reads = int(seg[-1])
+        ro = None
+        if read_off is not None:
+            ro = np.ascontiguousarray(read_off, dtype=np.uint64)
+            fixed_len = 0
+        h = C.c_void_p()
+        check(lib().gasm_batch_create(self.ctx.h, reads.ctypes.data_as(C.c_void_p),
+                                      ro.ctypes.data_as(C.c_void_p) if ro is not None else None, self.n_reads, int(fixed_len),
+                                      seg.ctypes.data_as(C.c_void_p), self.n_segments, C.byref(h)))
+        self.h = h
+        self.k = None
+        self._table = None
+
+    @classmethod
+    def from_strings(cls, segments, ctx=None):
+        """segments: list (one per segment) of lists of read strings"""
+        seg = np.zeros(len(segments) + 1, dtype=np.uint64)
+        off, data = [0], []
+        for i, rs in enumerate(segments):
+            seg[i + 1] = seg[i] + len(rs)
+            for r in rs:
+                b = r.encode() if isinstance(r, str) else bytes(r)
+                data.append(b)
+                off.append(off[-1] + len(b))
+        buf = np.frombuffer(b"".join(data), dtype=np.uint8) if data else np.zeros(0, dtype=np.uint8)
+        return cls(buf, seg, read_off=np.array(off, dtype=np.uint64), ctx=ctx)
+
+    def build(self, k, genome_len_hint=0):
+        check(lib().gasm_batch_build(self.h, int(k), int(genome_len_hint)))
+        self.k = int(k)
+        return self
+
+    def score(self, kmer=8, table=None):
+        t = np.ascontiguousarray(qtable.load_normalised() if table is None else table, dtype=np.float64)
+        if t.size != qtable.ROWS:
+            raise ValueError(f"table must hold {qtable.ROWS} probabilities")
+        self._table = t
+        check(lib().gasm_batch_score(self.h, int(kmer), t.ctypes.data_as(C.c_void_p)))
+        return self
+
+    def total_kmers(self):
+        return int(lib().gasm_batch_total_kmers(self.h))
+
+    def distinct(self):
+        """(seg_off[n_segments+1], keys uint64, multiplicities uint32, words)"""
+        so, ks, ms, w = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int()
+        check(lib().gasm_batch_fetch_distinct(self.h, C.byref(so), C.byref(ks), C.byref(ms), C.byref(w)))
+        seg = np.ctypeslib.as_array(C.cast(so, C.POINTER(C.c_uint64)), shape=(self.n_segments + 1,)).copy()
+        n = int(seg[-1])
+        keys = np.ctypeslib.as_array(C.cast(ks, C.POINTER(C.c_uint64)), shape=(n * w.value,)).copy() if n else np.zeros(0, np.uint64)
+        mult = np.ctypeslib.as_array(C.cast(ms, C.POINTER(C.c_uint32)), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        return seg, keys, mult, w.value
+
+    def distinct_kmers(self, segment):
+        seg, keys, mult, w = self.distinct()
+        a, b = int(seg[segment]), int(seg[segment + 1])
+        return unpack_kmers(keys[a * w:b * w], self.k, w), mult[a:b]
+
+    def contigs_raw(self):
+        """(seg_contig_off[n_segments+1], contig base offsets[n_contigs+1], ASCII bytes)"""
+        so, off, data = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib().gasm_batch_fetch_contigs(self.h, C.byref(so), C.byref(off), C.byref(data)))
+        seg = np.ctypeslib.as_array(C.cast(so, C.POINTER(C.c_uint64)), shape=(self.n_segments + 1,)).copy()
+        nc = int(seg[-1])
+        o = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), shape=(nc + 1,)).copy()
+        raw = C.string_at(data, int(o[-1])) if nc and o[-1] else b""
+        return seg, o, raw
+
+    def contigs(self, segment=None):
+        seg, o, raw = self.contigs_raw()
+        rng = range(self.n_segments) if segment is None else [segment]
+        out = [[raw[int(o[c]):int(o[c + 1])].decode() for c in range(int(seg[s]), int(seg[s + 1]))] for s in rng]
+        return out if segment is None else out[0]
+
+    def scores(self):
+        """dict of per-contig arrays, in contigs_raw() order"""
+        ps = [C.c_void_p() for _ in range(5)]
+        check(lib().gasm_batch_fetch_scores(self.h, *[C.byref(p) for p in ps]))
+        seg, _, _ = self.contigs_raw()
+        n = int(seg[-1])
+
+        def arr(p, ct):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).copy() if n else np.zeros(0, ct)
+        return dict(bp_score=arr(ps[0], C.c_double), bp_score_norm_by_break_freqs=arr(ps[1], C.c_double),
+                    bp_score_norm_by_len=arr(ps[2], C.c_double), kmer_breaks=arr(ps[3], C.c_int32),
+                    sequence_len=arr(ps[4], C.c_int32), seg_contig_off=seg)
+
+    def close(self):
+        if self.h:
+            lib().gasm_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

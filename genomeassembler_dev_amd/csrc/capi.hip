@@ -1,0 +1,335 @@
+// capi.hip — the extern "C" surface declared in include/gasm.h.
+#include <algorithm>
+#include <atomic>
+#include <new>
+#include <thread>
+
+#include "pipeline.h"
+
+struct gasm_strlist {
+    std::vector<char> data;
+    std::vector<u64> off;
+};
+
+struct gasm_contigs {
+    std::vector<char> data;
+    std::vector<u64> off;
+    u64 rows = 0;
+    std::vector<u32> perm;
+    int words = 1;
+    std::vector<u64> dkeys;
+    std::vector<u32> dmult;
+};
+
+struct gasm_scores {
+    u64 n = 0;
+    std::vector<int32_t> len, breaks, lev, startpos;
+    std::vector<double> bp, nf, nl, freq, pd;
+    std::vector<u64> pd_off;
+    bool has_freq = false, velvet = false;
+};
+
+struct gasm_batch {
+    gasm_ctx* ctx = nullptr;
+    DevReads rd;
+    BuildState bs;
+    DevPaths dp;
+    ScoreTable tb;
+    ScoreState ss;
+    bool built = false, paths_ready = false, table_set = false;
+    std::vector<double> table_copy;
+};
+
+#define API_GUARD_BEGIN try {
+#define API_GUARD_END                                                          \
+    } catch (const std::bad_alloc&) {                                          \
+        gasm_set_error("out of host memory");                                  \
+        return GASM_ERR_CAPACITY;                                              \
+    } catch (const std::exception& e) {                                        \
+        gasm_set_error("internal error: %s", e.what());                        \
+        return GASM_ERR_INVALID;                                               \
+    }
+
+static void strlist_from(const std::vector<std::string>& v, std::vector<char>& data, std::vector<u64>& off) {
+    off.assign(v.size() + 1, 0);
+    size_t tot = 0;
+    for (size_t i = 0; i < v.size(); ++i) { tot += v[i].size(); off[i + 1] = tot; }
+    data.resize(tot);
+    for (size_t i = 0; i < v.size(); ++i) memcpy(data.data() + off[i], v[i].data(), v[i].size());
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------- get_contigs
+int gasm_get_contigs(gasm_ctx* ctx, const char* kmers, uint64_t n_kmers, int dbg_kmer, int seed, int matrix_rows,
+                     gasm_contigs** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || (n_kmers && !kmers)) { gasm_set_error("gasm_get_contigs: null argument"); return GASM_ERR_INVALID; }
+    if (matrix_rows < 0) { gasm_set_error("matrix_rows must be >= 0"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    // the exploded k-mers are reads of length k with one k-mer each
+    DevReads rd;
+    BuildState bs;
+    const u64 seg_off[2] = {0, n_kmers};
+    int st = rd.upload(ctx, kmers, nullptr, n_kmers, (u32)dbg_kmer, seg_off, 1);
+    if (st == GASM_OK) st = pipeline_build(ctx, rd, dbg_kmer, 0, bs);
+    if (st == GASM_OK) st = pipeline_fetch_distinct(ctx, rd, bs);
+    if (st == GASM_OK) st = pipeline_fetch_contigs(ctx, rd, bs);
+    gasm_contigs* c = nullptr;
+    if (st == GASM_OK) {
+        c = new gasm_contigs();
+        c->data = bs.h_contigs;
+        c->off = bs.h_c_off;
+        c->words = 1;
+        c->dkeys = bs.h_dk_key;
+        c->dmult = bs.h_dk_cnt;
+        c->rows = (u64)matrix_rows;
+        // lib/DeNovoAssembler.cpp:195-203
+        gasm_host::shuffle_perm(bs.n_contigs, seed, (u64)matrix_rows, c->perm);
+    }
+    rd.release();
+    bs.release();
+    if (st != GASM_OK) return st;
+    *out = c;
+    return GASM_OK;
+    API_GUARD_END
+}
+
+uint64_t gasm_contigs_count(const gasm_contigs* c) { return c ? c->off.size() - 1 : 0; }
+const char* gasm_contigs_data(const gasm_contigs* c) { return c ? c->data.data() : nullptr; }
+const uint64_t* gasm_contigs_offsets(const gasm_contigs* c) { return c ? c->off.data() : nullptr; }
+uint64_t gasm_contigs_rows(const gasm_contigs* c) { return c ? c->rows : 0; }
+const uint32_t* gasm_contigs_perm(const gasm_contigs* c) { return c ? c->perm.data() : nullptr; }
+uint64_t gasm_contigs_distinct_count(const gasm_contigs* c) { return c ? c->dmult.size() : 0; }
+int gasm_contigs_key_words(const gasm_contigs* c) { return c ? c->words : 0; }
+const uint64_t* gasm_contigs_distinct_keys(const gasm_contigs* c) { return c ? c->dkeys.data() : nullptr; }
+const uint32_t* gasm_contigs_distinct_mult(const gasm_contigs* c) { return c ? c->dmult.data() : nullptr; }
+void gasm_contigs_free(gasm_contigs* c) { delete c; }
+
+// -------------------------------------------------------------------------------------------- assemble_contigs
+static int assemble_common(const char* contigs, const u64* off, u64 n, const u32* perm, u64 rows, u64 row_len, int k, gasm_strlist** out) {
+    std::vector<std::string> c(n);
+    for (u64 i = 0; i < n; ++i) c[i].assign(contigs + off[i], contigs + off[i + 1]);
+    for (u64 i = 0; i < rows * row_len; ++i)
+        if (perm[i] >= n) { gasm_set_error("perm[%llu] = %u out of range", (unsigned long long)i, perm[i]); return GASM_ERR_INVALID; }
+    std::vector<std::string> res;
+    GCHK(gasm_host::assemble(c, perm, rows, row_len, k, res));
+    gasm_strlist* s = new gasm_strlist();
+    strlist_from(res, s->data, s->off);
+    *out = s;
+    return GASM_OK;
+}
+
+int gasm_assemble_contigs(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, const uint32_t* perm,
+                          uint64_t rows, uint64_t row_len, int dbg_kmer, gasm_strlist** out) {
+    API_GUARD_BEGIN
+    (void)ctx;  // host algorithm in this version
+    if (!out || !off || (n && !contigs) || (rows && row_len && !perm)) { gasm_set_error("gasm_assemble_contigs: null argument"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    return assemble_common(contigs, off, n, perm, rows, row_len, dbg_kmer, out);
+    API_GUARD_END
+}
+
+int gasm_assemble_contigs_velvet(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, int dbg_kmer, int seed,
+                                 int rows, gasm_strlist** out) {
+    API_GUARD_BEGIN
+    (void)ctx;
+    if (!out || !off || (n && !contigs) || rows < 0) { gasm_set_error("gasm_assemble_contigs_velvet: bad argument"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    std::vector<u32> perm;
+    gasm_host::shuffle_perm(n, seed, (u64)rows, perm);  // lib/BreakageScorer.cpp:86-94
+    return assemble_common(contigs, off, n, perm.data(), (u64)rows, n, dbg_kmer, out);
+    API_GUARD_END
+}
+
+uint64_t gasm_strlist_count(const gasm_strlist* s) { return s ? s->off.size() - 1 : 0; }
+const char* gasm_strlist_data(const gasm_strlist* s) { return s ? s->data.data() : nullptr; }
+const uint64_t* gasm_strlist_offsets(const gasm_strlist* s) { return s ? s->off.data() : nullptr; }
+void gasm_strlist_free(gasm_strlist* s) { delete s; }
+
+// -------------------------------------------------------------------------------------------- calc_breakscore
+int gasm_levenshtein(const char* query, uint64_t nq, const char* target, uint64_t nt, int infix, int32_t* out) {
+    API_GUARD_BEGIN
+    if (!out || (nq && !query) || (nt && !target)) { gasm_set_error("gasm_levenshtein: null argument"); return GASM_ERR_INVALID; }
+    *out = gasm_host::levenshtein(query, nq, target, nt, infix != 0);
+    return GASM_OK;
+    API_GUARD_END
+}
+
+int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_off, uint64_t n_paths, const char* reads,
+                         const uint64_t* read_off, uint64_t n_reads, const char* true_solution, uint64_t true_len, int kmer,
+                         const char* bp_kmer, const uint64_t* bp_off, uint64_t n_table, const double* bp_prob, int variant,
+                         int flags, gasm_scores** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || !path_off || !read_off || !bp_off || (n_table && (!bp_kmer || !bp_prob)) || (true_len && !true_solution)) {
+        gasm_set_error("gasm_calc_breakscore: null argument");
+        return GASM_ERR_INVALID;
+    }
+    if (variant != GASM_SCORE_OWN && variant != GASM_SCORE_VELVET) { gasm_set_error("unknown variant %d", variant); return GASM_ERR_INVALID; }
+    if (n_paths > 0xFFFFFFF0ull) { gasm_set_error("too many paths"); return GASM_ERR_CAPACITY; }
+    *out = nullptr;
+    const bool velvet = variant == GASM_SCORE_VELVET;
+    DevReads rd;
+    DevPaths dp;
+    ScoreTable tb;
+    ScoreState ss;
+    const u64 seg_off[2] = {0, n_reads};
+    static const char empty = 0;
+    int st = rd.upload(ctx, reads ? reads : &empty, read_off, n_reads, 0, seg_off, 1);
+    if (st == GASM_OK) st = dp.upload_ascii(ctx, paths ? paths : &empty, path_off, (u32)n_paths);
+    if (st == GASM_OK) st = tb.set(ctx, bp_kmer, bp_off, n_table, bp_prob);
+    if (st == GASM_OK) st = pipeline_score_launch(ctx, rd, dp, kmer, tb, !velvet && (flags & GASM_WANT_FREQ), velvet, ss);
+    if (st == GASM_OK) st = pipeline_score_fetch(ctx, ss);
+    gasm_scores* s = nullptr;
+    if (st == GASM_OK) {
+        s = new gasm_scores();
+        s->n = n_paths;
+        s->velvet = velvet;
+        s->len = ss.h_len; s->breaks = ss.h_breaks; s->bp = ss.h_bp; s->nf = ss.h_nf; s->nl = ss.h_nl;
+        s->lev.assign(n_paths, 0);
+        if (!velvet && (flags & GASM_WANT_FREQ)) { s->freq = ss.h_freq; s->has_freq = true; }
+        if (velvet) {
+            s->pd = ss.h_pd;
+            s->pd_off = ss.h_pd_off;
+            // lib/BreakageScorer.cpp:273-274: start of the path inside the true solution, taken only when a read matched
+            s->startpos.assign(n_paths, 0);
+            const std::string truth(true_solution ? true_solution : "", true_len);
+            for (u64 p = 0; p < n_paths; ++p) {
+                if (ss.h_breaks[p] <= 0) continue;
+                const std::string pth(paths + path_off[p], paths + path_off[p + 1]);
+                s->startpos[p] = (int32_t)(int)truth.find(pth);
+            }
+        }
+        if (flags & GASM_WANT_LEV) {
+            // lib/DeNovoAssembler.cpp:463 (global) / lib/BreakageScorer.cpp:339 (infix); threads over paths
+            std::atomic<u64> next(0);
+            unsigned nt = std::thread::hardware_concurrency();
+            nt = std::max(1u, std::min(nt, 32u));
+            if (n_paths < 2) nt = 1;
+            auto work = [&]() {
+                while (true) {
+                    const u64 p = next.fetch_add(1);
+                    if (p >= n_paths) break;
+                    s->lev[p] = gasm_host::levenshtein(paths + path_off[p], path_off[p + 1] - path_off[p], true_solution, true_len, velvet);
+                }
+            };
+            if (nt == 1) work();
+            else {
+                std::vector<std::thread> th;
+                for (unsigned t = 0; t < nt; ++t) th.emplace_back(work);
+                for (auto& t : th) t.join();
+            }
+        }
+    }
+    rd.release(); dp.release(); tb.release(); ss.release();
+    if (st != GASM_OK) return st;
+    *out = s;
+    return GASM_OK;
+    API_GUARD_END
+}
+
+uint64_t gasm_scores_count(const gasm_scores* s) { return s ? s->n : 0; }
+const int32_t* gasm_scores_sequence_len(const gasm_scores* s) { return s ? s->len.data() : nullptr; }
+const double* gasm_scores_bp_score(const gasm_scores* s) { return s ? s->bp.data() : nullptr; }
+const double* gasm_scores_norm_by_break_freqs(const gasm_scores* s) { return s ? s->nf.data() : nullptr; }
+const double* gasm_scores_norm_by_len(const gasm_scores* s) { return s ? s->nl.data() : nullptr; }
+const int32_t* gasm_scores_kmer_breaks(const gasm_scores* s) { return s ? s->breaks.data() : nullptr; }
+const int32_t* gasm_scores_lev_dist(const gasm_scores* s) { return s ? s->lev.data() : nullptr; }
+const double* gasm_scores_path_freq(const gasm_scores* s) { return s && s->has_freq ? s->freq.data() : nullptr; }
+const int32_t* gasm_scores_startpos(const gasm_scores* s) { return s && s->velvet ? s->startpos.data() : nullptr; }
+const double* gasm_scores_prob_dist(const gasm_scores* s) { return s && s->velvet ? s->pd.data() : nullptr; }
+const uint64_t* gasm_scores_prob_dist_offsets(const gasm_scores* s) { return s && s->velvet ? s->pd_off.data() : nullptr; }
+void gasm_scores_free(gasm_scores* s) { delete s; }
+
+// ------------------------------------------------------------------------------------------------------ batches
+int gasm_batch_create(gasm_ctx* ctx, const char* reads, const uint64_t* read_off, uint64_t n_reads, uint32_t fixed_len,
+                      const uint64_t* seg_read_off, uint32_t n_segments, gasm_batch** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out) { gasm_set_error("gasm_batch_create: null argument"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    gasm_batch* b = new gasm_batch();
+    b->ctx = ctx;
+    const int st = b->rd.upload(ctx, reads, read_off, n_reads, fixed_len, seg_read_off, n_segments);
+    if (st != GASM_OK) { gasm_batch_free(b); return st; }
+    *out = b;
+    return GASM_OK;
+    API_GUARD_END
+}
+
+void gasm_batch_free(gasm_batch* b) {
+    if (!b) return;
+    if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
+    b->rd.release(); b->bs.release(); b->dp.release(); b->tb.release(); b->ss.release();
+    delete b;
+}
+
+int gasm_batch_build(gasm_batch* b, int k, uint64_t genome_len_hint) {
+    API_GUARD_BEGIN
+    if (!b) { gasm_set_error("batch is null"); return GASM_ERR_INVALID; }
+    b->built = false; b->paths_ready = false; b->ss.valid = false; b->ss.launched = false;
+    GCHK(pipeline_build(b->ctx, b->rd, k, genome_len_hint, b->bs));
+    b->built = true;
+    return GASM_OK;
+    API_GUARD_END
+}
+
+int gasm_batch_score(gasm_batch* b, int kmer, const double* table) {
+    API_GUARD_BEGIN
+    if (!b || !table) { gasm_set_error("gasm_batch_score: null argument"); return GASM_ERR_INVALID; }
+    if (!b->built) { gasm_set_error("gasm_batch_score before gasm_batch_build"); return GASM_ERR_STATE; }
+    if (!b->table_set || memcmp(b->table_copy.data(), table, GASM_TABLE_ROWS * sizeof(double)) != 0) {
+        GCHK(b->tb.set_standard(b->ctx, table));
+        b->table_copy.assign(table, table + GASM_TABLE_ROWS);
+        b->table_set = true;
+    }
+    if (!b->paths_ready) {
+        GCHK(pipeline_contig_paths(b->ctx, b->rd, b->bs, b->dp));
+        b->paths_ready = true;
+    }
+    return pipeline_score_launch(b->ctx, b->rd, b->dp, kmer, b->tb, false, false, b->ss);
+    API_GUARD_END
+}
+
+uint64_t gasm_batch_total_kmers(const gasm_batch* b) { return b ? b->bs.n_kmers : 0; }
+uint64_t gasm_batch_total_reads(const gasm_batch* b) { return b ? b->rd.n_reads : 0; }
+
+int gasm_batch_fetch_distinct(gasm_batch* b, const uint64_t** seg_off, const uint64_t** keys, const uint32_t** mult, int* words) {
+    API_GUARD_BEGIN
+    if (!b || !seg_off || !keys || !mult || !words) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
+    if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
+    GCHK(pipeline_fetch_distinct(b->ctx, b->rd, b->bs));
+    *seg_off = b->bs.h_seg_doff.data();
+    *keys = b->bs.h_dk_key.data();
+    *mult = b->bs.h_dk_cnt.data();
+    *words = 1;
+    return GASM_OK;
+    API_GUARD_END
+}
+
+int gasm_batch_fetch_contigs(gasm_batch* b, const uint64_t** seg_contig_off, const uint64_t** off, const char** data) {
+    API_GUARD_BEGIN
+    if (!b || !seg_contig_off || !off || !data) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
+    if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
+    GCHK(pipeline_fetch_contigs(b->ctx, b->rd, b->bs));
+    *seg_contig_off = b->bs.h_seg_coff.data();
+    *off = b->bs.h_c_off.data();
+    *data = b->bs.h_contigs.data();
+    return GASM_OK;
+    API_GUARD_END
+}
+
+int gasm_batch_fetch_scores(gasm_batch* b, const double** bp_score, const double** norm_by_break_freqs, const double** norm_by_len,
+                            const int32_t** kmer_breaks, const int32_t** sequence_len) {
+    API_GUARD_BEGIN
+    if (!b || !bp_score || !norm_by_break_freqs || !norm_by_len || !kmer_breaks || !sequence_len) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
+    GCHK(pipeline_score_fetch(b->ctx, b->ss));
+    *bp_score = b->ss.h_bp.data();
+    *norm_by_break_freqs = b->ss.h_nf.data();
+    *norm_by_len = b->ss.h_nl.data();
+    *kmer_breaks = b->ss.h_breaks.data();
+    *sequence_len = b->ss.h_len.data();
+    return GASM_OK;
+    API_GUARD_END
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// ctx.cpp — context, error text, per-kernel HIP-event profiling.
+#include "gasm_internal.h"
+
+static thread_local std::string g_err;
+
+void gasm_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" const char* gasm_last_error(void) { return g_err.c_str(); }
+extern "C" const char* gasm_version(void) { return "libgasm 0.1 (gfx950)"; }
+
+hipEvent_t gasm_ctx::ev_get() {
+    if (!ev_pool.empty()) {
+        hipEvent_t e = ev_pool.back();
+        ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void gasm_ctx::prof_begin(const char* name, hipEvent_t* a, hipEvent_t* b, int* stage) {
+    auto it = stage_ix.find(name);
+    if (it == stage_ix.end()) {
+        ProfStage s;
+        s.name = name;
+        stages.push_back(s);
+        it = stage_ix.emplace(name, (int)stages.size() - 1).first;
+    }
+    *stage = it->second;
+    *a = ev_get();
+    *b = ev_get();
+    (void)hipEventRecord(*a, stream);
+}
+
+void gasm_ctx::prof_end(int stage, hipEvent_t a, hipEvent_t b) {
+    (void)hipEventRecord(b, stream);
+    pending.push_back({stage, a, b});
+}
+
+int gasm_ctx::prof_collect() {
+    HIPCHK(hipStreamSynchronize(stream));
+    for (auto& p : pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            stages[p.stage].ms += ms;
+            stages[p.stage].launches += 1;
+        }
+        ev_pool.push_back(p.a);
+        ev_pool.push_back(p.b);
+    }
+    pending.clear();
+    return GASM_OK;
+}
+
+extern "C" int gasm_ctx_create(int device, gasm_ctx** out) {
+    if (!out) { gasm_set_error("gasm_ctx_create: out is null"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        gasm_set_error("no HIP device available (%s); libgasm has no CPU fallback", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return GASM_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { gasm_set_error("device %d out of range (have %d)", device, n); return GASM_ERR_NO_DEVICE; }
+    if (hipSetDevice(device) != hipSuccess) { gasm_set_error("hipSetDevice(%d) failed", device); return GASM_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { gasm_set_error("hipGetDeviceProperties failed"); return GASM_ERR_NO_DEVICE; }
+    if (!strstr(prop.gcnArchName, "gfx950")) {
+        gasm_set_error("device %d is %s; libgasm is built for gfx950 only", device, prop.gcnArchName);
+        return GASM_ERR_NO_DEVICE;
+    }
+    gasm_ctx* c = new gasm_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        gasm_set_error("hipStreamCreate failed");
+        return GASM_ERR_NO_DEVICE;
+    }
+    c->h_pin_words = 1 << 16;
+    if (hipHostMalloc((void**)&c->h_pin, c->h_pin_words * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        gasm_set_error("hipHostMalloc failed");
+        return GASM_ERR_NO_DEVICE;
+    }
+    *out = c;
+    return GASM_OK;
+}
+
+extern "C" void gasm_ctx_destroy(gasm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int gasm_ctx_sync(gasm_ctx* c) {
+    if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GASM_OK;
+}
+
+extern "C" void* gasm_ctx_stream(gasm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+extern "C" int gasm_profile_enable(gasm_ctx* c, int on) {
+    if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
+    if (!on && c->prof) GCHK(c->prof_collect());
+    c->prof = on != 0;
+    return GASM_OK;
+}
+
+extern "C" int gasm_profile_reset(gasm_ctx* c) {
+    if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
+    GCHK(c->prof_collect());
+    for (auto& s : c->stages) { s.ms = 0; s.launches = 0; }
+    return GASM_OK;
+}
+
+extern "C" int gasm_profile_read(gasm_ctx* c, int* n, const char* const** names, const double** ms, const uint64_t** launches) {
+    if (!c || !n || !names || !ms || !launches) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
+    GCHK(c->prof_collect());
+    c->out_names.clear(); c->out_ms.clear(); c->out_launches.clear();
+    for (auto& s : c->stages) { c->out_names.push_back(s.name.c_str()); c->out_ms.push_back(s.ms); c->out_launches.push_back(s.launches); }
+    *n = (int)c->stages.size();
+    *names = c->out_names.data();
+    *ms = c->out_ms.data();
+    *launches = c->out_launches.data();
+    return GASM_OK;
+}

@@ -1,0 +1,90 @@
+// device_utils.h — device-side helpers shared by the kernels (gfx950, wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+#define GASM_WG 256                    // threads per workgroup of the streaming kernels (4 waves)
+#define GASM_EMPTY64 0xFFFFFFFFFFFFFFFFull
+#define GASM_NONE32 0xFFFFFFFFu
+
+// ----------------------------------------------------------------------------------------------------------------
+// Packed base streams.  Base j of a stream lives in 64-bit word j>>5 at bit 62-2*(j&31) (first base most
+// significant), A=0 C=1 G=2 T=3, so a window read as an integer compares like the string.  Every stream is followed
+// by two zero padding words so a window may read one word past its last base.
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 window32(const u64* __restrict__ w, u64 p) {
+    const u64 i = p >> 5;
+    const u32 s = (u32)(p & 31) << 1;
+    const u64 hi = w[i];
+    const u64 lo = w[i + 1];
+    // (lo >> 64) is undefined; split the shift so s == 0 yields hi
+    return (hi << s) | ((lo >> 1) >> (63 - s));
+}
+
+// the k bases starting at p as a right-aligned 2k-bit integer, k <= 32
+__device__ __forceinline__ u64 kmer_at(const u64* __restrict__ w, u64 p, int k) { return window32(w, p) >> (64 - 2 * k); }
+
+__device__ __forceinline__ u32 base_code(u8 c) { return ((c >> 1) & 3u) ^ ((c >> 2) & 1u); }  // A0 C1 G2 T3
+__device__ __forceinline__ bool base_ok(u8 c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+
+__device__ __forceinline__ u32 hash64(u64 x) { return (u32)((x * 0x9E3779B97F4A7C15ull) >> 32); }
+
+// ----------------------------------------------------------------------------------------------------------------
+// Block-wide exclusive scan of one u32 per thread, GASM_WG (=256) threads = 4 waves.  s_tmp: >= 5 u32 of LDS.
+// Returns the exclusive prefix; *total gets the block sum.  Contains two barriers.
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 wave_incl_scan(u32 v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+template <int NT>
+__device__ __forceinline__ u32 block_excl_scan(u32 v, u32* s_tmp, u32* total) {
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 inc = wave_incl_scan(v);
+    if (lane == 63) s_tmp[wv] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const u32 t = s_tmp[i];
+        if (i < wv) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+template <class T>
+__device__ __forceinline__ u32 lower_bound_dev(const T* __restrict__ a, u32 lo, u32 hi, T t) {
+    while (lo < hi) {
+        const u32 m = (lo + hi) >> 1;
+        if (a[m] < t) lo = m + 1;
+        else hi = m;
+    }
+    return lo;
+}
+
+// largest i in [0, n) with a[i] <= t, for a[0] <= t
+template <class T>
+__device__ __forceinline__ u32 upper_seg(const T* __restrict__ a, u32 n, T t) {
+    u32 lo = 0, hi = n;  // invariant a[lo] <= t < a[hi] (a[n] = +inf)
+    while (hi - lo > 1) {
+        const u32 m = (lo + hi) >> 1;
+        if (a[m] <= t) lo = m;
+        else hi = m;
+    }
+    return lo;
+}

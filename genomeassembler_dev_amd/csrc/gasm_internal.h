@@ -1,0 +1,120 @@
+// gasm_internal.h — shared host-side plumbing of libgasm (context, device buffers, launch + profiling helpers).
+// Device code lives in the .hip files; nothing here is visible through include/gasm.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gasm.h"
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef uint16_t u16;
+typedef uint8_t u8;
+
+void gasm_set_error(const char* fmt, ...);
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            gasm_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return GASM_ERR_HIP;                                                                       \
+        }                                                                                              \
+    } while (0)
+
+#define GCHK(expr)                \
+    do {                          \
+        int _s = (expr);          \
+        if (_s != GASM_OK) return _s; \
+    } while (0)
+
+// Grow-only device allocation.  Steady-state steps of the same shape never call hipMalloc.
+struct DBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return GASM_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 16 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            gasm_set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            p = nullptr;
+            return GASM_ERR_HIP;
+        }
+        cap = want;
+        return GASM_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ProfStage {
+    std::string name;
+    double ms = 0;
+    u64 launches = 0;
+};
+
+struct gasm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int n_cu = 256;
+    // small pinned host area for read-backs of counters/flags
+    u64* h_pin = nullptr;
+    size_t h_pin_words = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfStage> stages;
+    std::map<std::string, int> stage_ix;
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> ev_pool;
+    // read-out storage for gasm_profile_read
+    std::vector<const char*> out_names;
+    std::vector<double> out_ms;
+    std::vector<u64> out_launches;
+
+    hipEvent_t ev_get();
+    void prof_begin(const char* name, hipEvent_t* a, hipEvent_t* b, int* stage);
+    void prof_end(int stage, hipEvent_t a, hipEvent_t b);
+    int prof_collect();  // syncs and folds pending pairs into stages
+};
+
+// Launch helper: optional HIP-event bracket per launch (stage = kernel name), launch error check.
+#define GLAUNCH(ctx, name, kern, grid, block, shmem, ...)                                    \
+    do {                                                                                     \
+        hipEvent_t _a = nullptr, _b = nullptr;                                               \
+        int _st = -1;                                                                        \
+        if ((ctx)->prof) (ctx)->prof_begin(name, &_a, &_b, &_st);                            \
+        hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__);            \
+        if ((ctx)->prof) (ctx)->prof_end(_st, _a, _b);                                       \
+        HIPCHK(hipGetLastError());                                                           \
+    } while (0)
+
+static inline u32 ceil_div_u64(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
+static inline u32 next_pow2_u32(u32 x) {
+    u32 p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// ---- host algorithms (host_algos.cpp) ------------------------------------------------------------------------
+namespace gasm_host {
+// std::shuffle permutations exactly as lib/DeNovoAssembler.cpp:195-203 draws them (indices instead of strings).
+void shuffle_perm(u64 n, int seed, u64 rows, std::vector<u32>& perm);
+// greedy merge + ordering of lib/DeNovoAssembler.cpp:228-304; returns GASM_ERR_RANGE where substr would throw.
+int assemble(const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k, std::vector<std::string>& out);
+// Myers bit-parallel edit distance; infix = edlib HW mode, else NW.
+int levenshtein(const char* q, u64 nq, const char* t, u64 nt, bool infix);
+}  // namespace gasm_host

@@ -1,0 +1,71 @@
+// kernels.h — kernel declarations and the small POD views passed to them by value.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_utils.h"
+
+// Reads of all segments of a batch, packed 2-bit in one base stream.
+struct ReadSet {
+    const u64* words;          // packed bases (+2 padding words)
+    const u64* read_off;       // n_reads+1 base offsets, or nullptr when fixed_len > 0
+    const u64* seg_read_off;   // n_segments+1 read indices
+    const u32* seg_tile_start; // n_segments+1 tile indices (depends on the tile width of the launch)
+    u32 fixed_len;
+    u32 n_segments;
+};
+
+// Sorted distinct k-mers (= distinct edges) of all segments, dense, with the per-(segment,bucket) directory.
+struct GraphView {
+    const u64* dk_key;   // D_total keys, sorted inside each segment
+    const u32* dstart;   // n_segments * 2^bbits + 1
+    int k;
+    int bbits;
+};
+
+// Paths (contigs or caller-supplied sequences) of all segments, packed, for scoring.
+struct PathSet {
+    const u64* words;        // packed bases of all paths, concatenated without gaps (+2 padding words)
+    const u64* p_off;        // n_paths+1 base offsets
+    const u32* seg_path_off; // n_segments+1 path indices
+    u32 n_segments;
+};
+
+#define GASM_KT 16          // k-mers per thread and round of k_bucket_scatter
+#define GASM_TBL 4096       // slots of the LDS de-duplication table
+#define GASM_TBL_LIMIT 2816 // distinct keys one bucket may hold before the host re-partitions
+
+// ---- kernels_build.hip
+__global__ void k_pack_ascii(const u8* ascii, u64 nbases, u64* words, u64 nwords, u32* err);
+__global__ void k_bucket_hist(ReadSet rs, int k, int bbits, u32 g, u32 n_tiles, u32* hist);
+template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
+__global__ void k_copy_u64(const u64* a, u64* b, u32 n);
+__global__ void k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 n_tiles, u64* cursor, u64* keys);
+__global__ void k_bucket_dedup(u64* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow);
+__global__ void k_bucket_gather(const u64* keys, const u32* mult, const u64* bstart, const u32* dstart, u64* dk_key,
+                                u32* dk_cnt);
+__global__ void k_node_flags(GraphView gv, u8* eflag);
+__global__ void k_edge_next(GraphView gv, const u8* eflag, u32* nxt, u64* link);
+__global__ void k_link_jump(const u8* eflag, u64* link, u32 n_edges);
+__global__ void k_chain_len(const u8* eflag, const u32* nxt, const u64* link, u32* clen, u32 n_edges);
+__global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u32* e_cid, u64* e_coff, u32* seg_ncontig,
+                              u64* seg_cbases);
+__global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* clen, const u32* seg_cstart,
+                               const u64* seg_bstart, u32* e_cid, u64* e_coff, u64* c_off);
+__global__ void k_contig_emit(GraphView gv, const u8* eflag, const u64* link, const u64* e_coff, u8* out, u32 n_edges);
+
+// ---- kernels_score.hip
+struct SeedTable {
+    u64* seed;            // slot -> seed value
+    u32* gpos;            // slot -> global base position of the window (GASM_NONE32 = empty)
+    const u64* tbl_off;   // n_segments+1 slot offsets; every segment's table size is a power of two
+};
+__global__ void k_seed_insert(PathSet ps, SeedTable st, const u64* seg_base_off, int w);
+__global__ void k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, u32* poscnt,
+                             u32* total);
+__global__ void k_path_reduce(PathSet ps, const u32* poscnt, const u32* total, const double* dprob, int kmer,
+                              double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,
+                              int32_t* seq_len, u32 n_paths);
+__global__ void k_path_freq(PathSet ps, const u32* poscnt, const u32* total, const int32_t* drow, int kmer, u32 n_table,
+                            u32* freq_cnt, u32 n_paths);
+__global__ void k_prob_dist(PathSet ps, const double* dprob, int kmer, const u64* pd_off, double* out, u32 n_paths);

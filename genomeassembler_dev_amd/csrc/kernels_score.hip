@@ -1,0 +1,180 @@
+// kernels_score.hip — breakage scoring kernels (gfx950).
+//
+// The reference scores a path by, for every unique read, std::string::find(read) in the path (first occurrence
+// only), turning the hit position into an octamer window and accumulating count x probability
+// (lib/DeNovoAssembler.cpp:346-426).  Same results, different route:
+//   k_seed_insert  hash index of every path position by its first w bases (w = min(32, shortest read))
+//   k_read_match   one thread per read: candidates from the index in increasing position order, full 2-bit
+//                  compare, first hit per path -> integer counters per path position (:360, :389-390)
+//   k_path_reduce  per path: sum over positions of count x prob(window(position)) in a fixed order (:394-426)
+// Reads are not de-duplicated first: the reference does that (:334-337) only to save work, a read occurring c times
+// adds c to the same counter either way.
+// Counting per *position* instead of per table row makes the sums integer-exact up to the final FP64 reduction,
+// which runs in a fixed lane/tree order: results are bit-reproducible run to run (the reference's own order is its
+// hash map's iteration order, hence the 1e-9 tolerance of the parity tests).
+#include "device_utils.h"
+#include "kernels.h"
+
+// Direct-address probability table over all ACGT strings of length 1..8: index = (4^L - 4)/3 + value.
+#define GASM_DIRECT_ROWS 87380
+__device__ __forceinline__ u32 direct_base(u32 L) { return ((1u << (2 * L)) - 4u) / 3u; }
+
+// Window of the break at hit position j (lib/DeNovoAssembler.cpp:366-386).  Returns false when the window is empty
+// (only for an empty path); *idx is the direct-table index of the (possibly end-truncated) window.
+__device__ __forceinline__ bool break_window(const u64* __restrict__ words, u64 pbase, u32 plen, u32 j, int kmer, u32* idx) {
+    const int st = (int)j - kmer / 2;
+    const u32 start = st > 0 ? (u32)st : 0u;
+    u32 width = 8;
+    if (start == 0) {
+        if (j == 1) width = 2;
+        else if (j == 2) width = 4;
+        else if (j == 3) width = 6;
+    }
+    if (start >= plen) return false;
+    const u32 avail = plen - start;
+    const u32 wd = width < avail ? width : avail;
+    *idx = direct_base(wd) + (u32)kmer_at(words, pbase + start, (int)wd);
+    return true;
+}
+
+__global__ void __launch_bounds__(GASM_WG) k_seed_insert(PathSet ps, SeedTable st, const u64* __restrict__ seg_base_off, int w) {
+    const u32 seg = blockIdx.y;
+    const u64 lo = seg_base_off[seg], hi = seg_base_off[seg + 1];
+    const u64 g = lo + (u64)blockIdx.x * GASM_WG + threadIdx.x;
+    if (g + (u64)w > hi) return;
+    const u64 seed = kmer_at(ps.words, g, w);
+    const u64 tb = st.tbl_off[seg];
+    const u32 mask = (u32)(st.tbl_off[seg + 1] - tb) - 1;
+    u32 h = hash64(seed) & mask;
+    while (true) {
+        const u32 old = atomicCAS(&st.gpos[tb + h], GASM_NONE32, (u32)g);
+        if (old == GASM_NONE32) { st.seed[tb + h] = seed; break; }
+        h = (h + 1) & mask;
+    }
+}
+
+__global__ void __launch_bounds__(GASM_WG) k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* __restrict__ seg_base_off,
+                                                        int w, u32* __restrict__ poscnt, u32* __restrict__ total) {
+    const u32 seg = blockIdx.y;
+    const u64 r = rs.seg_read_off[seg] + (u64)blockIdx.x * GASM_WG + threadIdx.x;
+    if (r >= rs.seg_read_off[seg + 1]) return;
+    u64 p0; u32 len;
+    if (rs.fixed_len) { p0 = r * rs.fixed_len; len = rs.fixed_len; }
+    else { p0 = rs.read_off[r]; len = (u32)(rs.read_off[r + 1] - p0); }
+    if (len < (u32)w || len == 0) return;
+    const u64 seed = kmer_at(rs.words, p0, w);
+    const u64 tb = st.tbl_off[seg];
+    const u32 mask = (u32)(st.tbl_off[seg + 1] - tb) - 1;
+    const u32 h0 = hash64(seed) & mask;
+    const u32 pfirst = ps.seg_path_off[seg], plast = ps.seg_path_off[seg + 1];
+    if (pfirst == plast) return;
+    (void)seg_base_off;
+    long long last_g = -1;
+    u32 last_path = GASM_NONE32;
+    while (true) {
+        // smallest candidate position beyond the last one handled, among the slots of this probe sequence
+        u32 best = GASM_NONE32;
+        u32 h = h0;
+        while (true) {
+            const u32 gp = st.gpos[tb + h];
+            if (gp == GASM_NONE32) break;
+            if ((long long)gp > last_g && gp < best && st.seed[tb + h] == seed) best = gp;
+            h = (h + 1) & mask;
+        }
+        if (best == GASM_NONE32) break;
+        last_g = best;
+        const u32 c = pfirst + upper_seg<u64>(ps.p_off + pfirst, plast - pfirst, (u64)best);
+        if (c == last_path) continue;  // an earlier position of this path already matched (first occurrence wins)
+        if ((u64)best + len > ps.p_off[c + 1]) continue;
+        bool same = true;
+        for (u32 o = 0; o < len && same; o += 32) {
+            const u32 nbase = len - o < 32 ? len - o : 32;
+            const u64 a = window32(rs.words, p0 + o), b = window32(ps.words, (u64)best + o);
+            same = ((a ^ b) >> (64 - 2 * nbase)) == 0;
+        }
+        if (!same) continue;
+        last_path = c;
+        atomicAdd(&poscnt[best], 1u);
+        atomicAdd(&total[c], 1u);
+    }
+}
+
+__device__ __forceinline__ double wave_sum_fixed(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+// One wave per path.  Lane l sums positions l, l+64, ... in order; the 64 partials are combined by a fixed butterfly.
+__global__ void __launch_bounds__(GASM_WG) k_path_reduce(PathSet ps, const u32* __restrict__ poscnt, const u32* __restrict__ total,
+                                                         const double* __restrict__ dprob, int kmer, double* __restrict__ bp_score,
+                                                         double* __restrict__ norm_freq, double* __restrict__ norm_len,
+                                                         int32_t* __restrict__ kmer_breaks, int32_t* __restrict__ seq_len, u32 n_paths) {
+    const u32 p = blockIdx.x * (GASM_WG / 64) + (threadIdx.x >> 6);
+    if (p >= n_paths) return;
+    const u32 lane = threadIdx.x & 63;
+    const u64 pb = ps.p_off[p];
+    const u32 len = (u32)(ps.p_off[p + 1] - pb);
+    const u32 tot = total[p];
+    const double dtot = (double)tot;
+    double s1 = 0.0, s2 = 0.0;
+    for (u32 j = lane; j < len; j += 64) {
+        const u32 c = poscnt[pb + j];
+        if (c) {
+            u32 idx;
+            if (break_window(ps.words, pb, len, j, kmer, &idx)) {
+                const double pr = dprob[idx];
+                s1 += pr * (double)c;
+                s2 += pr * ((double)c / dtot);
+            }
+        }
+    }
+    s1 = wave_sum_fixed(s1);
+    s2 = wave_sum_fixed(s2);
+    if (lane == 0) {
+        bp_score[p] = s1;
+        norm_freq[p] = s2;
+        norm_len[p] = s1 / (double)(int32_t)len;
+        kmer_breaks[p] = (int32_t)tot;
+        seq_len[p] = (int32_t)len;
+    }
+}
+
+// Dense per-row break counts (for the reference's path_freq output): freq_cnt[p * n_table + row] += count.
+__global__ void __launch_bounds__(GASM_WG) k_path_freq(PathSet ps, const u32* __restrict__ poscnt, const u32* __restrict__ total,
+                                                       const int32_t* __restrict__ drow, int kmer, u32 n_table,
+                                                       u32* __restrict__ freq_cnt, u32 n_paths) {
+    const u32 p = blockIdx.x * (GASM_WG / 64) + (threadIdx.x >> 6);
+    if (p >= n_paths) return;
+    (void)total;
+    const u32 lane = threadIdx.x & 63;
+    const u64 pb = ps.p_off[p];
+    const u32 len = (u32)(ps.p_off[p + 1] - pb);
+    for (u32 j = lane; j < len; j += 64) {
+        const u32 c = poscnt[pb + j];
+        if (c) {
+            u32 idx;
+            if (break_window(ps.words, pb, len, j, kmer, &idx)) {
+                const int32_t row = drow[idx];
+                if (row >= 0) atomicAdd(&freq_cnt[(u64)p * n_table + row], c);
+            }
+        }
+    }
+}
+
+// lib/BreakageScorer.cpp:200-215: probability of the kmer-long window at every path position.
+__global__ void __launch_bounds__(GASM_WG) k_prob_dist(PathSet ps, const double* __restrict__ dprob, int kmer,
+                                                       const u64* __restrict__ pd_off, double* __restrict__ out, u32 n_paths) {
+    const u32 p = blockIdx.x * (GASM_WG / 64) + (threadIdx.x >> 6);
+    if (p >= n_paths) return;
+    const u32 lane = threadIdx.x & 63;
+    const u64 pb = ps.p_off[p];
+    const u32 len = (u32)(ps.p_off[p + 1] - pb);
+    const u32 n = (u32)(pd_off[p + 1] - pd_off[p]);
+    (void)len;
+    for (u32 j = lane; j < n; j += 64) {
+        double v = 0.0;
+        if (kmer >= 1 && kmer <= 8) v = dprob[direct_base((u32)kmer) + (u32)kmer_at(ps.words, pb + j, kmer)];
+        out[pd_off[p] + j] = v;
+    }
+}

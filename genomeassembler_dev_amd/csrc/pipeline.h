@@ -1,0 +1,93 @@
+// pipeline.h — host-side state of the device pipeline (reads -> distinct k-mers -> graph -> contigs -> scores).
+#pragma once
+#include "gasm_internal.h"
+#include "kernels.h"
+
+// Reads of one or more segments, resident in HBM as one packed base stream.
+struct DevReads {
+    u32 n_segments = 0;
+    u64 n_reads = 0, total_bases = 0;
+    u32 fixed_len = 0;
+    u32 min_len = 0, max_len = 0;          // over non-empty reads (0 if none)
+    u64 n_empty = 0;
+    std::vector<u64> h_read_off;            // ragged only
+    std::vector<u64> h_seg_read_off;        // n_segments+1
+    std::vector<u64> h_seg_empty;           // empty reads per segment
+    DBuf d_words, d_read_off, d_seg_read_off;
+    // tile directory cache (depends on reads per tile)
+    u32 tiles_ipt = 0, n_tiles = 0;
+    std::vector<u32> h_seg_tile_start;
+    DBuf d_seg_tile_start;
+
+    int upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off,
+               u32 n_segments);
+    int set_tiles(gasm_ctx* ctx, u32 ipt);
+    ReadSet view() const;
+    u64 read_len(u64 r) const { return fixed_len ? fixed_len : h_read_off[r + 1] - h_read_off[r]; }
+    void release();
+};
+
+// Paths to score (contigs produced by a build, or caller-supplied sequences).
+struct DevPaths {
+    u32 n_segments = 0, n_paths = 0;
+    u64 total_bases = 0;
+    std::vector<u64> h_p_off;               // n_paths+1
+    std::vector<u32> h_seg_path_off;        // n_segments+1
+    std::vector<u64> h_seg_base_off;        // n_segments+1: first base of each segment's paths
+    DBuf d_words, d_p_off, d_seg_path_off, d_seg_base_off;
+    // set when the object owns packed words built from an ASCII stream already on the device
+    int pack_from_device_ascii(gasm_ctx* ctx, const u8* d_ascii);
+    int upload_ascii(gasm_ctx* ctx, const char* data, const u64* off, u32 n_paths);
+    int upload_dirs(gasm_ctx* ctx);
+    PathSet view() const;
+    void release();
+};
+
+struct BuildState {
+    int k = 0, bbits = 0;
+    u64 n_kmers = 0;
+    u32 d_total = 0, n_contigs = 0;
+    u64 contig_bases = 0;
+    std::vector<u32> h_dstart;              // n_segments*nb+1
+    std::vector<u32> h_seg_cstart;          // n_segments+1
+    std::vector<u64> h_seg_bstart;          // n_segments+1
+    DBuf d_keys, d_mult, d_hist, d_bstart, d_cursor, d_bucket_d, d_dstart, d_flags;
+    DBuf d_dk_key, d_dk_cnt, d_eflag, d_nxt, d_link, d_clen, d_ecid, d_ecoff;
+    DBuf d_seg_ncontig, d_seg_cbases, d_seg_cstart, d_seg_bstart, d_c_off, d_contig_ascii;
+    // host copies filled by fetch
+    std::vector<u64> h_seg_doff, h_dk_key, h_c_off, h_seg_coff;
+    std::vector<u32> h_dk_cnt;
+    std::vector<char> h_contigs;
+    bool fetched_distinct = false, fetched_contigs = false;
+    void release();
+};
+
+struct ScoreTable {
+    // direct-address tables over ACGT strings of length 1..8 (87 380 rows)
+    DBuf d_prob, d_row;
+    u32 n_table = 0;
+    int set(gasm_ctx* ctx, const char* bp_kmer, const u64* bp_off, u64 n_table, const double* bp_prob);
+    int set_standard(gasm_ctx* ctx, const double* table69904);
+    void release();
+};
+
+struct ScoreState {
+    DBuf d_tbl_off, d_seed, d_gpos, d_poscnt, d_total, d_out_f64, d_out_i32, d_freq, d_pd_off, d_pd, d_seg_empty;
+    std::vector<u64> h_toff;
+    u32 n_paths = 0, n_table = 0;
+    bool want_freq = false, want_pd = false, launched = false;
+    std::vector<double> h_bp, h_nf, h_nl, h_freq, h_pd;
+    std::vector<int32_t> h_breaks, h_len;
+    std::vector<u64> h_pd_off;
+    bool valid = false;
+    void release();
+};
+
+int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 genome_len_hint, BuildState& bs);
+int pipeline_fetch_distinct(gasm_ctx* ctx, const DevReads& rd, BuildState& bs);
+int pipeline_fetch_contigs(gasm_ctx* ctx, const DevReads& rd, BuildState& bs);
+// paths of the build as a DevPaths (packs the contig text on the device)
+int pipeline_contig_paths(gasm_ctx* ctx, const DevReads& rd, const BuildState& bs, DevPaths& dp);
+int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, const ScoreTable& tb, bool want_freq,
+                          bool want_pd, ScoreState& ss);
+int pipeline_score_fetch(gasm_ctx* ctx, ScoreState& ss);

@@ -1,0 +1,575 @@
+// pipeline.hip — host orchestration of the device pipeline.  All launches go to the ctx stream; the host only waits
+// where a size is needed to allocate the next stage (distinct count, contig bytes) and at fetch time.
+#include "pipeline.h"
+
+#include <algorithm>
+
+// ---------------------------------------------------------------------------------------------------------------
+// small local kernels
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void k_set_u64(u64* p, u64 v) { *p = v; }
+
+// empty reads match every path at position 0 (std::string::find("") == 0, lib/DeNovoAssembler.cpp:360)
+__global__ void k_add_empty_reads(PathSet ps, const u64* __restrict__ seg_empty, u32* __restrict__ poscnt, u32* __restrict__ total) {
+    const u32 seg = blockIdx.y;
+    const u32 p = ps.seg_path_off[seg] + blockIdx.x * GASM_WG + threadIdx.x;
+    if (p >= ps.seg_path_off[seg + 1]) return;
+    const u32 e = (u32)seg_empty[seg];
+    if (!e) return;
+    total[p] += e;
+    if (ps.p_off[p + 1] > ps.p_off[p]) poscnt[ps.p_off[p]] += e;
+}
+
+static int h2d(gasm_ctx* ctx, DBuf& b, const void* src, size_t bytes) {
+    GCHK(b.ensure(bytes ? bytes : 8));
+    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GASM_OK;
+}
+
+static int pack_ascii(gasm_ctx* ctx, const u8* d_ascii, u64 nbases, DBuf& words, u32* d_err) {
+    const u64 nw = (nbases + 31) / 32;
+    GCHK(words.ensure((nw + 2) * 8));
+    HIPCHK(hipMemsetAsync((u64*)words.p + nw, 0, 16, ctx->stream));
+    if (nw) GLAUNCH(ctx, "k_pack_ascii", k_pack_ascii, dim3(ceil_div_u64(nw, GASM_WG)), dim3(GASM_WG), 0, d_ascii, nbases,
+                    words.as<u64>(), nw, d_err);
+    return GASM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// DevReads
+// ---------------------------------------------------------------------------------------------------------------
+int DevReads::upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 n, u32 flen, const u64* seg_off, u32 S) {
+    if (!ctx) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
+    if (S == 0 || !seg_off) { gasm_set_error("need at least one segment and seg_read_off"); return GASM_ERR_INVALID; }
+    if (S > 65535) { gasm_set_error("at most 65535 segments per batch (got %u)", S); return GASM_ERR_CAPACITY; }
+    if (!read_off && flen == 0 && n) { gasm_set_error("give read_off or fixed_len"); return GASM_ERR_INVALID; }
+    if (seg_off[0] != 0 || seg_off[S] != n) { gasm_set_error("seg_read_off must run from 0 to n_reads"); return GASM_ERR_INVALID; }
+    for (u32 s = 0; s < S; ++s) if (seg_off[s] > seg_off[s + 1]) { gasm_set_error("seg_read_off not monotone"); return GASM_ERR_INVALID; }
+    HIPCHK(hipSetDevice(ctx->device));
+    n_segments = S; n_reads = n; fixed_len = read_off ? 0 : flen;
+    h_seg_read_off.assign(seg_off, seg_off + S + 1);
+    h_seg_empty.assign(S, 0);
+    n_empty = 0; min_len = 0; max_len = 0;
+    const char* base = reads;
+    if (read_off) {
+        h_read_off.resize(n + 1);
+        for (u64 r = 0; r <= n; ++r) {
+            if (r && read_off[r] < read_off[r - 1]) { gasm_set_error("read_off not monotone"); return GASM_ERR_INVALID; }
+            h_read_off[r] = read_off[r] - read_off[0];
+        }
+        base = reads + read_off[0];
+        total_bases = h_read_off[n];
+        u32 s = 0;
+        for (u64 r = 0; r < n; ++r) {
+            while (r >= h_seg_read_off[s + 1]) ++s;
+            const u64 L = h_read_off[r + 1] - h_read_off[r];
+            if (L > 0xFFFFFFFFull) { gasm_set_error("read longer than 2^32"); return GASM_ERR_CAPACITY; }
+            if (L == 0) { ++n_empty; ++h_seg_empty[s]; continue; }
+            if (min_len == 0 || L < min_len) min_len = (u32)L;
+            if (L > max_len) max_len = (u32)L;
+        }
+    } else {
+        h_read_off.clear();
+        total_bases = n * (u64)flen;
+        if (n) { min_len = max_len = flen; }
+    }
+    if (n && !reads && total_bases) { gasm_set_error("reads is null"); return GASM_ERR_INVALID; }
+    DBuf ascii, err;
+    GCHK(err.ensure(8));
+    HIPCHK(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+    GCHK(h2d(ctx, ascii, base, total_bases));
+    int st = pack_ascii(ctx, ascii.as<u8>(), total_bases, d_words, err.as<u32>());
+    u32 herr = 0;
+    if (st == GASM_OK && hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
+    if (st == GASM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { gasm_set_error("sync failed after packing"); st = GASM_ERR_HIP; }
+    ascii.release(); err.release();
+    if (st != GASM_OK) return st;
+    if (herr) { gasm_set_error("reads contain a base outside upper-case ACGT"); return GASM_ERR_NON_ACGT; }
+    if (!fixed_len) GCHK(h2d(ctx, d_read_off, h_read_off.data(), (n + 1) * 8));
+    GCHK(h2d(ctx, d_seg_read_off, h_seg_read_off.data(), (S + 1) * 8));
+    tiles_ipt = 0;
+    return GASM_OK;
+}
+
+int DevReads::set_tiles(gasm_ctx* ctx, u32 ipt) {
+    if (tiles_ipt == ipt) return GASM_OK;
+    std::vector<u32>& t = h_seg_tile_start;
+    t.assign(n_segments + 1, 0);
+    for (u32 s = 0; s < n_segments; ++s) {
+        const u64 rs = h_seg_read_off[s + 1] - h_seg_read_off[s];
+        const u64 nt = (rs + ipt - 1) / ipt;
+        if ((u64)t[s] + nt > 0xFFFFFFF0ull) { gasm_set_error("too many tiles"); return GASM_ERR_CAPACITY; }
+        t[s + 1] = t[s] + (u32)nt;
+    }
+    GCHK(h2d(ctx, d_seg_tile_start, t.data(), t.size() * 4));
+    n_tiles = t[n_segments];
+    tiles_ipt = ipt;
+    return GASM_OK;
+}
+
+ReadSet DevReads::view() const {
+    ReadSet v;
+    v.words = d_words.as<u64>();
+    v.read_off = fixed_len ? nullptr : d_read_off.as<u64>();
+    v.seg_read_off = d_seg_read_off.as<u64>();
+    v.seg_tile_start = d_seg_tile_start.as<u32>();
+    v.fixed_len = fixed_len;
+    v.n_segments = n_segments;
+    return v;
+}
+
+void DevReads::release() { d_words.release(); d_read_off.release(); d_seg_read_off.release(); d_seg_tile_start.release(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// DevPaths
+// ---------------------------------------------------------------------------------------------------------------
+int DevPaths::upload_dirs(gasm_ctx* ctx) {
+    GCHK(h2d(ctx, d_p_off, h_p_off.data(), h_p_off.size() * 8));
+    GCHK(h2d(ctx, d_seg_path_off, h_seg_path_off.data(), h_seg_path_off.size() * 4));
+    std::vector<u64>& sb = h_seg_base_off;
+    sb.resize(n_segments + 1);
+    for (u32 s = 0; s <= n_segments; ++s) sb[s] = h_p_off[h_seg_path_off[s]];
+    GCHK(h2d(ctx, d_seg_base_off, sb.data(), sb.size() * 8));
+    return GASM_OK;
+}
+
+int DevPaths::pack_from_device_ascii(gasm_ctx* ctx, const u8* d_ascii) {
+    DBuf err;
+    GCHK(err.ensure(8));
+    HIPCHK(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+    int st = pack_ascii(ctx, d_ascii, total_bases, d_words, err.as<u32>());
+    u32 herr = 0;
+    if (st == GASM_OK && hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
+    if (st == GASM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
+    err.release();
+    if (st != GASM_OK) return st;
+    if (herr) { gasm_set_error("paths contain a base outside upper-case ACGT"); return GASM_ERR_NON_ACGT; }
+    return GASM_OK;
+}
+
+int DevPaths::upload_ascii(gasm_ctx* ctx, const char* data, const u64* off, u32 np) {
+    n_segments = 1; n_paths = np;
+    h_p_off.resize((size_t)np + 1);
+    for (u32 i = 0; i <= np; ++i) {
+        if (i && off[i] < off[i - 1]) { gasm_set_error("path offsets not monotone"); return GASM_ERR_INVALID; }
+        h_p_off[i] = off[i] - off[0];
+    }
+    total_bases = h_p_off[np];
+    if (total_bases >= 0xFFFFFFF0ull) { gasm_set_error("paths exceed 2^32 bases"); return GASM_ERR_CAPACITY; }
+    h_seg_path_off = {0u, np};
+    DBuf ascii;
+    GCHK(h2d(ctx, ascii, data + off[0], total_bases));
+    int st = pack_from_device_ascii(ctx, ascii.as<u8>());
+    ascii.release();
+    GCHK(st);
+    return upload_dirs(ctx);
+}
+
+PathSet DevPaths::view() const {
+    PathSet v;
+    v.words = d_words.as<u64>();
+    v.p_off = d_p_off.as<u64>();
+    v.seg_path_off = d_seg_path_off.as<u32>();
+    v.n_segments = n_segments;
+    return v;
+}
+
+void DevPaths::release() { d_words.release(); d_p_off.release(); d_seg_path_off.release(); d_seg_base_off.release(); }
+
+void BuildState::release() {
+    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
+                    &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_seg_ncontig, &d_seg_cbases, &d_seg_cstart,
+                    &d_seg_bstart, &d_c_off, &d_contig_ascii})
+        b->release();
+}
+
+void ScoreState::release() {
+    for (DBuf* b : {&d_tbl_off, &d_seed, &d_gpos, &d_poscnt, &d_total, &d_out_f64, &d_out_i32, &d_freq, &d_pd_off, &d_pd, &d_seg_empty}) b->release();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// build
+// ---------------------------------------------------------------------------------------------------------------
+int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs) {
+    if (k < 2 || k > 31) { gasm_set_error("k = %d not supported by this build (2..31)", k); return GASM_ERR_INVALID; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const u32 S = rd.n_segments;
+    bs.fetched_distinct = bs.fetched_contigs = false;
+    bs.k = k;
+    // ---- sizes known on the host
+    u64 N = 0, maxNs = 0;
+    {
+        std::vector<u64> ns(S, 0);
+        if (rd.fixed_len) {
+            const u64 nk = rd.fixed_len >= (u32)k ? rd.fixed_len - k + 1 : 0;
+            for (u32 s = 0; s < S; ++s) ns[s] = (rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]) * nk;
+        } else {
+            u32 s = 0;
+            for (u64 r = 0; r < rd.n_reads; ++r) {
+                while (r >= rd.h_seg_read_off[s + 1]) ++s;
+                const u64 L = rd.h_read_off[r + 1] - rd.h_read_off[r];
+                if (L >= (u64)k) ns[s] += L - k + 1;
+            }
+        }
+        for (u64 v : ns) { N += v; maxNs = std::max(maxNs, v); }
+    }
+    bs.n_kmers = N;
+    const u32 nk_max = rd.max_len >= (u32)k ? rd.max_len - k + 1 : 0;
+    u32 g = next_pow2_u32((nk_max + GASM_KT - 1) / GASM_KT);
+    g = std::max(1u, std::min(64u, g));
+    const u32 ipt = GASM_WG / g;
+    GCHK(rd.set_tiles(ctx, ipt));
+    // bucket bits: aim at ~1400 distinct k-mers per bucket (the LDS table takes 2816)
+    const int bb_cap = std::min(10, 2 * (k - 1));
+    int bbits = 0;
+    {
+        const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
+        while (bbits < bb_cap && (dest >> bbits) > 1400) ++bbits;
+    }
+    GCHK(bs.d_flags.ensure(64));
+    bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
+    if (N == 0) {
+        bs.bbits = 0;
+        bs.h_dstart.assign((size_t)S + 1, 0);
+        bs.h_seg_cstart.assign((size_t)S + 1, 0);
+        bs.h_seg_bstart.assign((size_t)S + 1, 0);
+        GCHK(h2d(ctx, bs.d_dstart, bs.h_dstart.data(), bs.h_dstart.size() * 4));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return GASM_OK;
+    }
+    GCHK(bs.d_keys.ensure(N * 8));
+    GCHK(bs.d_mult.ensure(N * 4));
+    const ReadSet rs = rd.view();
+    const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * 16);
+    u32 nbt = 0;
+    while (true) {
+        const u32 nb = 1u << bbits;
+        nbt = S * nb;
+        GCHK(bs.d_hist.ensure((size_t)nbt * 4));
+        GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
+        GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
+        GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
+        GCHK(bs.d_dstart.ensure(((size_t)nbt + 1) * 4));
+        HIPCHK(hipMemsetAsync(bs.d_hist.p, 0, (size_t)nbt * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 64, ctx->stream));
+        GLAUNCH(ctx, "k_bucket_hist", k_bucket_hist, dim3(grid_tiles), dim3(GASM_WG), nb * 4, rs, k, bbits, g, rd.n_tiles,
+                bs.d_hist.as<u32>());
+        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
+        HIPCHK(hipMemcpyAsync(bs.d_cursor.p, bs.d_bstart.p, (size_t)nbt * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        const size_t lds = (size_t)GASM_KT * GASM_WG * 8 + (size_t)nb * 16 + 32 + (size_t)GASM_KT * GASM_WG * 2;
+        GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter, dim3(grid_tiles), dim3(GASM_WG), lds, rs, k, bbits, g, rd.n_tiles,
+                bs.d_cursor.as<u64>(), bs.d_keys.as<u64>());
+        GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+                bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>());
+        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt);
+        bs.h_dstart.resize((size_t)nbt + 1);
+        u32 hflags[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(bs.h_dstart.data(), bs.d_dstart.p, ((size_t)nbt + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(hflags, bs.d_flags.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (!hflags[0]) break;
+        if (bbits >= bb_cap) {
+            gasm_set_error("a k-mer bucket holds more than %d distinct k-mers even with %d bucket bits", GASM_TBL_LIMIT, bbits);
+            return GASM_ERR_CAPACITY;
+        }
+        bbits = std::min(bb_cap, bbits + 2);
+    }
+    bs.bbits = bbits;
+    const u32 nb = 1u << bbits;
+    const u32 D = bs.h_dstart[nbt];
+    bs.d_total = D;
+    u32 maxD = 0;
+    for (u32 s = 0; s < S; ++s) maxD = std::max(maxD, bs.h_dstart[(size_t)(s + 1) * nb] - bs.h_dstart[(size_t)s * nb]);
+    bs.h_seg_cstart.assign((size_t)S + 1, 0);
+    bs.h_seg_bstart.assign((size_t)S + 1, 0);
+    if (D == 0) return GASM_OK;
+    GCHK(bs.d_dk_key.ensure((size_t)D * 8));
+    GCHK(bs.d_dk_cnt.ensure((size_t)D * 4));
+    GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+            bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<u64>(), bs.d_dk_cnt.as<u32>());
+    // ---- graph
+    GCHK(bs.d_eflag.ensure(D));
+    GCHK(bs.d_nxt.ensure((size_t)D * 4));
+    GCHK(bs.d_link.ensure((size_t)D * 8));
+    GCHK(bs.d_clen.ensure((size_t)D * 4));
+    GCHK(bs.d_ecid.ensure((size_t)D * 4));
+    GCHK(bs.d_ecoff.ensure((size_t)D * 8));
+    GCHK(bs.d_seg_ncontig.ensure((size_t)S * 4));
+    GCHK(bs.d_seg_cbases.ensure((size_t)S * 8));
+    HIPCHK(hipMemsetAsync(bs.d_link.p, 0xFF, (size_t)D * 8, ctx->stream));
+    HIPCHK(hipMemsetAsync(bs.d_clen.p, 0, (size_t)D * 4, ctx->stream));
+    GraphView gv;
+    gv.dk_key = bs.d_dk_key.as<u64>();
+    gv.dstart = bs.d_dstart.as<u32>();
+    gv.k = k;
+    gv.bbits = bbits;
+    const dim3 grid_seg(ceil_div_u64(maxD, GASM_WG), S);
+    const dim3 grid_all(ceil_div_u64(D, GASM_WG));
+    GLAUNCH(ctx, "k_node_flags", k_node_flags, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>());
+    GLAUNCH(ctx, "k_edge_next", k_edge_next, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
+    int rounds = 1;
+    while ((1ull << rounds) < (u64)maxD) ++rounds;
+    rounds += 1;
+    for (int r = 0; r < rounds; ++r)
+        GLAUNCH(ctx, "k_link_jump", k_link_jump, grid_all, dim3(GASM_WG), 0, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), D);
+    GLAUNCH(ctx, "k_chain_len", k_chain_len, grid_all, dim3(GASM_WG), 0, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>(),
+            bs.d_clen.as<u32>(), D);
+    GLAUNCH(ctx, "k_contig_scan", k_contig_scan, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
+            bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_seg_ncontig.as<u32>(), bs.d_seg_cbases.as<u64>());
+    std::vector<u32> h_nc(S);
+    std::vector<u64> h_cb(S);
+    HIPCHK(hipMemcpyAsync(h_nc.data(), bs.d_seg_ncontig.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(h_cb.data(), bs.d_seg_cbases.p, (size_t)S * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (u32 s = 0; s < S; ++s) {
+        bs.h_seg_cstart[s + 1] = bs.h_seg_cstart[s] + h_nc[s];
+        bs.h_seg_bstart[s + 1] = bs.h_seg_bstart[s] + h_cb[s];
+    }
+    bs.n_contigs = bs.h_seg_cstart[S];
+    bs.contig_bases = bs.h_seg_bstart[S];
+    if (bs.contig_bases >= 0xFFFFFFF0ull) { gasm_set_error("contigs exceed 2^32 bases"); return GASM_ERR_CAPACITY; }
+    GCHK(h2d(ctx, bs.d_seg_cstart, bs.h_seg_cstart.data(), ((size_t)S + 1) * 4));
+    GCHK(h2d(ctx, bs.d_seg_bstart, bs.h_seg_bstart.data(), ((size_t)S + 1) * 8));
+    GCHK(bs.d_c_off.ensure(((size_t)bs.n_contigs + 1) * 8));
+    GCHK(bs.d_contig_ascii.ensure(bs.contig_bases + 64));
+    if (bs.n_contigs) {
+        GLAUNCH(ctx, "k_contig_place", k_contig_place, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
+                bs.d_seg_cstart.as<u32>(), bs.d_seg_bstart.as<u64>(), bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_c_off.as<u64>());
+    }
+    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, ctx->stream, bs.d_c_off.as<u64>() + bs.n_contigs, bs.contig_bases);
+    if (bs.n_contigs) {
+        GLAUNCH(ctx, "k_contig_emit", k_contig_emit, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
+                bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), D);
+    }
+    return GASM_OK;
+}
+
+int pipeline_fetch_distinct(gasm_ctx* ctx, const DevReads& rd, BuildState& bs) {
+    if (bs.fetched_distinct) return GASM_OK;
+    const u32 S = rd.n_segments, nb = 1u << bs.bbits;
+    bs.h_seg_doff.resize((size_t)S + 1);
+    for (u32 s = 0; s <= S; ++s) bs.h_seg_doff[s] = bs.h_dstart.empty() ? 0 : bs.h_dstart[(size_t)s * nb];
+    bs.h_dk_key.resize(bs.d_total);
+    bs.h_dk_cnt.resize(bs.d_total);
+    if (bs.d_total) {
+        HIPCHK(hipMemcpyAsync(bs.h_dk_key.data(), bs.d_dk_key.p, (size_t)bs.d_total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(bs.h_dk_cnt.data(), bs.d_dk_cnt.p, (size_t)bs.d_total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    bs.fetched_distinct = true;
+    return GASM_OK;
+}
+
+int pipeline_fetch_contigs(gasm_ctx* ctx, const DevReads& rd, BuildState& bs) {
+    if (bs.fetched_contigs) return GASM_OK;
+    const u32 S = rd.n_segments;
+    bs.h_seg_coff.resize((size_t)S + 1);
+    for (u32 s = 0; s <= S; ++s) bs.h_seg_coff[s] = bs.h_seg_cstart.empty() ? 0 : bs.h_seg_cstart[s];
+    bs.h_c_off.assign((size_t)bs.n_contigs + 1, 0);
+    bs.h_contigs.resize(bs.contig_bases);
+    if (bs.n_contigs) {
+        HIPCHK(hipMemcpyAsync(bs.h_c_off.data(), bs.d_c_off.p, ((size_t)bs.n_contigs + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(bs.h_contigs.data(), bs.d_contig_ascii.p, bs.contig_bases, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    bs.fetched_contigs = true;
+    return GASM_OK;
+}
+
+int pipeline_contig_paths(gasm_ctx* ctx, const DevReads& rd, const BuildState& bs, DevPaths& dp) {
+    const u32 S = rd.n_segments;
+    dp.n_segments = S;
+    dp.n_paths = bs.n_contigs;
+    dp.total_bases = bs.contig_bases;
+    dp.h_seg_path_off.assign(bs.h_seg_cstart.begin(), bs.h_seg_cstart.end());
+    if (dp.h_seg_path_off.size() != (size_t)S + 1) dp.h_seg_path_off.assign((size_t)S + 1, 0);
+    dp.h_p_off.assign((size_t)bs.n_contigs + 1, 0);
+    if (bs.n_contigs) {
+        HIPCHK(hipMemcpyAsync(dp.h_p_off.data(), bs.d_c_off.p, ((size_t)bs.n_contigs + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    GCHK(dp.pack_from_device_ascii(ctx, bs.d_contig_ascii.as<u8>()));
+    return dp.upload_dirs(ctx);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// score tables
+// ---------------------------------------------------------------------------------------------------------------
+#define DIRECT_ROWS 87380
+static inline u32 direct_base_h(u32 L) { return ((1u << (2 * L)) - 4u) / 3u; }
+
+int ScoreTable::set(gasm_ctx* ctx, const char* bp_kmer, const u64* bp_off, u64 nt, const double* bp_prob) {
+    if (nt > 0x7FFFFFFFull) { gasm_set_error("table too large"); return GASM_ERR_CAPACITY; }
+    std::vector<double> prob(DIRECT_ROWS, 0.0);
+    std::vector<int32_t> row(DIRECT_ROWS, -1);
+    for (u64 i = 0; i < nt; ++i) {
+        const u64 L = bp_off[i + 1] - bp_off[i];
+        if (L < 1 || L > 8) { gasm_set_error("bp_kmer[%llu] has length %llu; supported: 1..8", (unsigned long long)i, (unsigned long long)L); return GASM_ERR_INVALID; }
+        u32 v = 0;
+        for (u64 j = 0; j < L; ++j) {
+            const char c = bp_kmer[bp_off[i] + j];
+            u32 code;
+            switch (c) { case 'A': code = 0; break; case 'C': code = 1; break; case 'G': code = 2; break; case 'T': code = 3; break;
+                default: gasm_set_error("bp_kmer[%llu] holds a base outside ACGT", (unsigned long long)i); return GASM_ERR_NON_ACGT; }
+            v = (v << 2) | code;
+        }
+        const u32 idx = direct_base_h((u32)L) + v;
+        if (row[idx] >= 0) { gasm_set_error("bp_kmer[%llu] repeats an earlier key", (unsigned long long)i); return GASM_ERR_INVALID; }
+        row[idx] = (int32_t)i;
+        prob[idx] = bp_prob[i];
+    }
+    n_table = (u32)nt;
+    GCHK(h2d(ctx, d_prob, prob.data(), prob.size() * 8));
+    GCHK(h2d(ctx, d_row, row.data(), row.size() * 4));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GASM_OK;
+}
+
+int ScoreTable::set_standard(gasm_ctx* ctx, const double* t) {
+    std::vector<double> prob(DIRECT_ROWS, 0.0);
+    std::vector<int32_t> row(DIRECT_ROWS, -1);
+    u32 src = 0;
+    for (u32 L = 2; L <= 8; L += 2) {
+        const u32 n = 1u << (2 * L), b = direct_base_h(L);
+        for (u32 v = 0; v < n; ++v) { prob[b + v] = t[src]; row[b + v] = (int32_t)src; ++src; }
+    }
+    n_table = GASM_TABLE_ROWS;
+    GCHK(h2d(ctx, d_prob, prob.data(), prob.size() * 8));
+    GCHK(h2d(ctx, d_row, row.data(), row.size() * 4));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GASM_OK;
+}
+
+void ScoreTable::release() { d_prob.release(); d_row.release(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// score: pipeline_score_launch queues everything on the stream; pipeline_score_fetch copies the results back.
+// ---------------------------------------------------------------------------------------------------------------
+int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, const ScoreTable& tb, bool want_freq, bool want_pd,
+                          ScoreState& ss) {
+    if (kmer < 0) { gasm_set_error("kmer must be >= 0"); return GASM_ERR_INVALID; }
+    if (rd.n_segments != dp.n_segments) { gasm_set_error("reads and paths disagree on the number of segments"); return GASM_ERR_INVALID; }
+    HIPCHK(hipSetDevice(ctx->device));
+    ss.valid = false;
+    ss.n_paths = dp.n_paths;
+    ss.n_table = tb.n_table;
+    ss.want_freq = want_freq && tb.n_table;
+    ss.want_pd = want_pd;
+    const u32 S = rd.n_segments, P = dp.n_paths;
+    const u64 TB = dp.total_bases;
+    GCHK(ss.d_poscnt.ensure((TB + 1) * 4));
+    GCHK(ss.d_total.ensure(((size_t)P + 1) * 4));
+    GCHK(ss.d_out_f64.ensure(((size_t)P + 1) * 8 * 3));
+    GCHK(ss.d_out_i32.ensure(((size_t)P + 1) * 4 * 2));
+    HIPCHK(hipMemsetAsync(ss.d_poscnt.p, 0, (TB + 1) * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ss.d_total.p, 0, ((size_t)P + 1) * 4, ctx->stream));
+    const PathSet ps = dp.view();
+    const int w = (int)std::min<u32>(32, rd.min_len);
+    if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
+        // per-segment seed tables: power-of-two, at least twice the number of path positions
+        std::vector<u64>& toff = ss.h_toff;
+        toff.assign((size_t)S + 1, 0);
+        u64 max_bases = 0, max_reads = 0;
+        for (u32 s = 0; s < S; ++s) {
+            const u64 nbases = dp.h_seg_base_off[s + 1] - dp.h_seg_base_off[s];
+            u64 slots = 2;
+            while (slots < 2 * nbases) slots <<= 1;
+            toff[s + 1] = toff[s] + slots;
+            max_bases = std::max(max_bases, nbases);
+            max_reads = std::max(max_reads, rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]);
+        }
+        GCHK(h2d(ctx, ss.d_tbl_off, toff.data(), toff.size() * 8));
+        GCHK(ss.d_seed.ensure(toff[S] * 8));
+        GCHK(ss.d_gpos.ensure(toff[S] * 4));
+        HIPCHK(hipMemsetAsync(ss.d_gpos.p, 0xFF, toff[S] * 4, ctx->stream));
+        SeedTable st;
+        st.seed = ss.d_seed.as<u64>();
+        st.gpos = ss.d_gpos.as<u32>();
+        st.tbl_off = ss.d_tbl_off.as<u64>();
+        if (max_bases) {
+            GLAUNCH(ctx, "k_seed_insert", k_seed_insert, dim3(ceil_div_u64(max_bases, GASM_WG), S), dim3(GASM_WG), 0, ps, st,
+                    dp.d_seg_base_off.as<u64>(), w);
+            GLAUNCH(ctx, "k_read_match", k_read_match, dim3(ceil_div_u64(max_reads, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), ps, st,
+                    dp.d_seg_base_off.as<u64>(), w, ss.d_poscnt.as<u32>(), ss.d_total.as<u32>());
+        }
+    }
+    if (P && rd.n_empty) {
+        GCHK(h2d(ctx, ss.d_seg_empty, rd.h_seg_empty.data(), (size_t)S * 8));
+        u32 maxp = 0;
+        for (u32 s = 0; s < S; ++s) maxp = std::max(maxp, dp.h_seg_path_off[s + 1] - dp.h_seg_path_off[s]);
+        if (maxp) hipLaunchKernelGGL(k_add_empty_reads, dim3(ceil_div_u64(maxp, GASM_WG), S), dim3(GASM_WG), 0, ctx->stream, ps,
+                                     ss.d_seg_empty.as<u64>(), ss.d_poscnt.as<u32>(), ss.d_total.as<u32>());
+    }
+    double* o_bp = ss.d_out_f64.as<double>();
+    double* o_nf = o_bp + (P + 1);
+    double* o_nl = o_nf + (P + 1);
+    int32_t* o_br = ss.d_out_i32.as<int32_t>();
+    int32_t* o_ln = o_br + (P + 1);
+    if (P) {
+        GLAUNCH(ctx, "k_path_reduce", k_path_reduce, dim3(ceil_div_u64(P, GASM_WG / 64)), dim3(GASM_WG), 0, ps, ss.d_poscnt.as<u32>(),
+                ss.d_total.as<u32>(), tb.d_prob.as<double>(), kmer, o_bp, o_nf, o_nl, o_br, o_ln, P);
+    }
+    if (P && ss.want_freq) {
+        const size_t cells = (size_t)P * tb.n_table;
+        GCHK(ss.d_freq.ensure(cells * 4));
+        HIPCHK(hipMemsetAsync(ss.d_freq.p, 0, cells * 4, ctx->stream));
+        GLAUNCH(ctx, "k_path_freq", k_path_freq, dim3(ceil_div_u64(P, GASM_WG / 64)), dim3(GASM_WG), 0, ps, ss.d_poscnt.as<u32>(),
+                ss.d_total.as<u32>(), tb.d_row.as<int32_t>(), kmer, tb.n_table, ss.d_freq.as<u32>(), P);
+    }
+    ss.h_pd_off.clear();
+    if (want_pd) {
+        ss.h_pd_off.assign((size_t)P + 1, 0);
+        for (u32 p = 0; p < P; ++p) {
+            const u64 len = dp.h_p_off[p + 1] - dp.h_p_off[p];
+            ss.h_pd_off[p + 1] = ss.h_pd_off[p] + (len >= (u64)kmer ? len - kmer + 1 : 0);
+        }
+        if (P) {
+            GCHK(h2d(ctx, ss.d_pd_off, ss.h_pd_off.data(), ss.h_pd_off.size() * 8));
+            GCHK(ss.d_pd.ensure((ss.h_pd_off[P] + 1) * 8));
+            GLAUNCH(ctx, "k_prob_dist", k_prob_dist, dim3(ceil_div_u64(P, GASM_WG / 64)), dim3(GASM_WG), 0, ps, tb.d_prob.as<double>(), kmer,
+                    ss.d_pd_off.as<u64>(), ss.d_pd.as<double>(), P);
+        }
+    }
+    ss.launched = true;
+    return GASM_OK;
+}
+
+int pipeline_score_fetch(gasm_ctx* ctx, ScoreState& ss) {
+    if (!ss.launched) { gasm_set_error("no scoring has been queued"); return GASM_ERR_STATE; }
+    if (ss.valid) return GASM_OK;
+    const u32 P = ss.n_paths;
+    double* o_bp = ss.d_out_f64.as<double>();
+    double* o_nf = o_bp + (P + 1);
+    double* o_nl = o_nf + (P + 1);
+    int32_t* o_br = ss.d_out_i32.as<int32_t>();
+    int32_t* o_ln = o_br + (P + 1);
+    ss.h_bp.resize(P); ss.h_nf.resize(P); ss.h_nl.resize(P); ss.h_breaks.resize(P); ss.h_len.resize(P);
+    ss.h_freq.clear(); ss.h_pd.clear();
+    std::vector<u32> h_fc;
+    if (P) {
+        HIPCHK(hipMemcpyAsync(ss.h_bp.data(), o_bp, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ss.h_nf.data(), o_nf, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ss.h_nl.data(), o_nl, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ss.h_breaks.data(), o_br, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ss.h_len.data(), o_ln, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (ss.want_freq) {
+            h_fc.resize((size_t)P * ss.n_table);
+            HIPCHK(hipMemcpyAsync(h_fc.data(), ss.d_freq.p, h_fc.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (ss.want_pd && ss.h_pd_off[P]) {
+            ss.h_pd.resize(ss.h_pd_off[P]);
+            HIPCHK(hipMemcpyAsync(ss.h_pd.data(), ss.d_pd.p, ss.h_pd_off[P] * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!h_fc.empty()) {
+        // observed_breaks = count / total (lib/DeNovoAssembler.cpp:402); 0/0 = NaN as in the reference
+        ss.h_freq.resize(h_fc.size());
+        for (u32 p = 0; p < P; ++p) {
+            const double tot = (double)ss.h_breaks[p];
+            for (u32 j = 0; j < ss.n_table; ++j) ss.h_freq[(size_t)p * ss.n_table + j] = (double)h_fc[(size_t)p * ss.n_table + j] / tot;
+        }
+    }
+    ss.valid = true;
+    return GASM_OK;
+}

@@ -1,0 +1,183 @@
+/* gasm.h — C ABI of libgasm, the MI355X (gfx950) implementation of the de Bruijn graph + k-meric breakage scoring
+ * hot path of SahakyanLab/GenomeAssembler_dev.
+ *
+ * This header is the drop-in boundary.  The reference crosses exactly one FFI: R -> C++ through Rcpp::sourceCpp
+ * (`// [[Rcpp::export]]` in lib/DeNovoAssembler.cpp:85,214,316 and lib/BreakageScorer.cpp:79,185).  Every entry
+ * point below names the exported reference function it replaces; integration/DeNovoAssemblerHIP.cpp (shown in
+ * INTEGRATION.md) is the Rcpp glue a maintainer would source instead of the reference file.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or torch types cross this boundary;
+ *   - every function returns GASM_OK (0) or a negative gasm_status; gasm_last_error() (thread-local) has the text;
+ *     no exception ever leaves the library (the reference's C++ exceptions become R errors through Rcpp's
+ *     BEGIN_RCPP/END_RCPP; the glue re-raises a non-zero status as Rcpp::stop);
+ *   - string lists are one byte buffer + n+1 uint64 offsets (string i = data[off[i] .. off[i+1]));
+ *   - results are library-allocated objects read through accessors and released with their *_free;
+ *   - bases are upper-case ACGT.  2-bit packing cannot hold anything else: other bytes return GASM_ERR_NON_ACGT
+ *     (documented divergence: the reference would silently create new hash keys);
+ *   - a gasm_ctx owns one GPU (device ordinal given at creation), one HIP stream and its scratch memory; calls on one
+ *     ctx must not overlap in time, different ctxs are independent.  There is no CPU fallback: without a usable
+ *     gfx950 device gasm_ctx_create fails with GASM_ERR_NO_DEVICE.
+ */
+#ifndef GASM_H
+#define GASM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gasm_status {
+    GASM_OK = 0,
+    GASM_ERR_INVALID = -1,    /* bad argument (null pointer, k out of range, inconsistent sizes) */
+    GASM_ERR_NON_ACGT = -2,   /* a base outside upper-case ACGT */
+    GASM_ERR_NO_DEVICE = -3,  /* no usable gfx950 GPU / HIP runtime error at start-up */
+    GASM_ERR_HIP = -4,        /* HIP runtime error during a call */
+    GASM_ERR_CAPACITY = -5,   /* input exceeds a documented limit */
+    GASM_ERR_RANGE = -6,      /* the reference would throw std::out_of_range here (substr past the end) */
+    GASM_ERR_STATE = -7       /* call order violated (e.g. score before build) */
+} gasm_status;
+
+#define GASM_MAX_K 63          /* k-mer keys are 64-bit for k <= 31 and 128-bit for 32 <= k <= 63 */
+#define GASM_TABLE_ROWS 69904  /* 4^2 + 4^4 + 4^6 + 4^8 rows of the breakage table, in that order, each lexicographic */
+
+typedef struct gasm_ctx gasm_ctx;
+typedef struct gasm_contigs gasm_contigs;
+typedef struct gasm_strlist gasm_strlist;
+typedef struct gasm_scores gasm_scores;
+typedef struct gasm_batch gasm_batch;
+
+const char* gasm_last_error(void);
+const char* gasm_version(void);
+
+int gasm_ctx_create(int device, gasm_ctx** out);
+void gasm_ctx_destroy(gasm_ctx* ctx);
+/* waits for everything queued on the ctx stream */
+int gasm_ctx_sync(gasm_ctx* ctx);
+/* the ctx's hipStream_t as an opaque pointer (for callers that time with their own HIP events) */
+void* gasm_ctx_stream(gasm_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * get_contigs(read_kmers, dbg_kmer, seed)                       replaces lib/DeNovoAssembler.cpp:86-206
+ *   kmers/n_kmers : the exploded k-mers, each exactly dbg_kmer characters, concatenated (what
+ *                   lib/DeNovoAssembler.R:109-130 builds); duplicates allowed, order irrelevant.
+ *   matrix_rows   : the reference's baked-in 10 000 (lib/DeNovoAssembler.cpp:195); 0 skips the shuffle.
+ * Result: the sorted unique contigs (the value of `contigs` after :192) and the shuffle matrix of :195-203 as
+ * matrix_rows x count indices into them (row-major).  The shuffle is std::shuffle with std::mt19937(seed) on the
+ * host, exactly as the reference draws it.
+ * Graph by-products kept for parity checks: the distinct k-mers (sorted, = the distinct edge list) with their
+ * multiplicities, 2-bit packed big-endian in `words` 64-bit words per k-mer (1 for k<=31, else 2; base 0 is the most
+ * significant pair of the k-mer's 2k bits).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gasm_get_contigs(gasm_ctx* ctx, const char* kmers, uint64_t n_kmers, int dbg_kmer, int seed, int matrix_rows,
+                     gasm_contigs** out);
+uint64_t gasm_contigs_count(const gasm_contigs* c);
+const char* gasm_contigs_data(const gasm_contigs* c);
+const uint64_t* gasm_contigs_offsets(const gasm_contigs* c);       /* count+1 */
+uint64_t gasm_contigs_rows(const gasm_contigs* c);
+const uint32_t* gasm_contigs_perm(const gasm_contigs* c);          /* rows*count */
+uint64_t gasm_contigs_distinct_count(const gasm_contigs* c);
+int gasm_contigs_key_words(const gasm_contigs* c);
+const uint64_t* gasm_contigs_distinct_keys(const gasm_contigs* c); /* distinct_count*words */
+const uint32_t* gasm_contigs_distinct_mult(const gasm_contigs* c); /* distinct_count */
+void gasm_contigs_free(gasm_contigs* c);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * assemble_contigs(contig_matrix, dbg_kmer)                      replaces lib/DeNovoAssembler.cpp:215-305
+ *   the matrix is `rows` rows of `row_len` entries (perm, row-major indices into the `n` distinct strings); for
+ *   get_contigs' output every row is a permutation of all n contigs, so row_len == n.
+ * assemble_contigs(velvet_contigs, dbg_kmer, seed)               replaces lib/BreakageScorer.cpp:80-174
+ *   rows = the reference's baked-in 20 000 (lib/BreakageScorer.cpp:86).
+ * Result: distinct scaffolds, longest first (same std::sort call as the reference).  GASM_ERR_RANGE where the
+ * reference's substr would throw (a contig shorter than the overlap being tried).
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gasm_assemble_contigs(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, const uint32_t* perm,
+                          uint64_t rows, uint64_t row_len, int dbg_kmer, gasm_strlist** out);
+int gasm_assemble_contigs_velvet(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, int dbg_kmer,
+                                 int seed, int rows, gasm_strlist** out);
+uint64_t gasm_strlist_count(const gasm_strlist* s);
+const char* gasm_strlist_data(const gasm_strlist* s);
+const uint64_t* gasm_strlist_offsets(const gasm_strlist* s);
+void gasm_strlist_free(gasm_strlist* s);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * calc_breakscore(path, sequencing_reads, true_solution, kmer, bp_kmer, bp_prob)
+ *   variant GASM_SCORE_OWN    replaces lib/DeNovoAssembler.cpp:317-477  (returns path_freq)
+ *   variant GASM_SCORE_VELVET replaces lib/BreakageScorer.cpp:186-353   (returns path_prob_dist(+_startpos),
+ *                                                                         Levenshtein in infix mode)
+ * flags: GASM_WANT_LEV computes lev_dist_vs_true (else zeros); GASM_WANT_FREQ materialises the dense path_freq
+ * (n_paths x n_table doubles, in bp_kmer order — the reference emits them in hash-iteration order, so only the
+ * multiset per path is defined there).
+ * bp_kmer keys must be distinct ACGT strings of length 1..8 (the reference tables hold lengths 2,4,6,8).
+ * Scores are FP64, summed in a fixed order (deterministic run to run); the reference sums in hash-iteration order,
+ * hence the 1e-9 absolute tolerance of the parity tests.
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define GASM_SCORE_OWN 0
+#define GASM_SCORE_VELVET 1
+#define GASM_WANT_LEV 1
+#define GASM_WANT_FREQ 2
+int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_off, uint64_t n_paths,
+                         const char* reads, const uint64_t* read_off, uint64_t n_reads, const char* true_solution,
+                         uint64_t true_len, int kmer, const char* bp_kmer, const uint64_t* bp_off, uint64_t n_table,
+                         const double* bp_prob, int variant, int flags, gasm_scores** out);
+uint64_t gasm_scores_count(const gasm_scores* s);
+const int32_t* gasm_scores_sequence_len(const gasm_scores* s);
+const double* gasm_scores_bp_score(const gasm_scores* s);
+const double* gasm_scores_norm_by_break_freqs(const gasm_scores* s);
+const double* gasm_scores_norm_by_len(const gasm_scores* s);
+const int32_t* gasm_scores_kmer_breaks(const gasm_scores* s);
+const int32_t* gasm_scores_lev_dist(const gasm_scores* s);
+const double* gasm_scores_path_freq(const gasm_scores* s);          /* count*n_table or NULL */
+const int32_t* gasm_scores_startpos(const gasm_scores* s);          /* velvet variant, else NULL */
+const double* gasm_scores_prob_dist(const gasm_scores* s);          /* velvet: concatenated, see offsets */
+const uint64_t* gasm_scores_prob_dist_offsets(const gasm_scores* s);/* count+1 */
+void gasm_scores_free(gasm_scores* s);
+
+/* Levenshtein distance as the reference takes it from edlib (lib/DeNovoAssembler.cpp:41-55 global,
+ * lib/BreakageScorer.cpp:41-55 infix); 0 for an empty operand, like the reference's failure branch. */
+int gasm_levenshtein(const char* query, uint64_t nq, const char* target, uint64_t nt, int infix, int32_t* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Segment batches: the reads-in / contigs+scores-out surface for many independent segments at once (the reference
+ * loops `for(i in 1:total_iters)` over independent segments, scripts/02_Real_vs_rand_prob_own.R:33-53).  No
+ * reference function takes reads directly: k-mer extraction is R code (lib/DeNovoAssembler.R:109-130); here it is
+ * the first kernel.  All data stays in HBM between the three calls; only gasm_batch_fetch_* copies back.
+ *
+ *   reads        : all reads of all segments, concatenated ASCII, segment after segment
+ *   read_off     : n_reads+1 offsets, or NULL when every read has fixed_len bases
+ *   seg_read_off : n_segments+1 indices into the read list
+ * gasm_batch_build(k)  : k-mers -> distinct k-mers + multiplicities -> (k-1)-mer graph -> contigs, per segment
+ *                        (get_contigs without the shuffle; results identical to calling it per segment)
+ * gasm_batch_score     : calc_breakscore (own variant, without Levenshtein/path_freq) of every segment's contigs
+ *                        against that segment's reads; table = GASM_TABLE_ROWS normalised probabilities
+ * Both queue work on the ctx stream and return; gasm_ctx_sync (or any fetch) waits.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gasm_batch_create(gasm_ctx* ctx, const char* reads, const uint64_t* read_off, uint64_t n_reads, uint32_t fixed_len,
+                      const uint64_t* seg_read_off, uint32_t n_segments, gasm_batch** out);
+void gasm_batch_free(gasm_batch* b);
+/* genome_len_hint: expected distinct k-mers per segment (0 = derive from the k-mer count); only sizes buckets */
+int gasm_batch_build(gasm_batch* b, int k, uint64_t genome_len_hint);
+int gasm_batch_score(gasm_batch* b, int kmer, const double* table);
+uint64_t gasm_batch_total_kmers(const gasm_batch* b);   /* k-mers extracted by the last build */
+uint64_t gasm_batch_total_reads(const gasm_batch* b);
+
+/* results of the last build (host copies, valid until the next build/free) */
+int gasm_batch_fetch_distinct(gasm_batch* b, const uint64_t** seg_off /*n_segments+1*/, const uint64_t** keys,
+                              const uint32_t** mult, int* words);
+int gasm_batch_fetch_contigs(gasm_batch* b, const uint64_t** seg_contig_off /*n_segments+1*/, const uint64_t** off,
+                             const char** data);
+/* results of the last score: one entry per contig, in the order of gasm_batch_fetch_contigs */
+int gasm_batch_fetch_scores(gasm_batch* b, const double** bp_score, const double** norm_by_break_freqs,
+                            const double** norm_by_len, const int32_t** kmer_breaks, const int32_t** sequence_len);
+
+/* Per-kernel device time of the stages of build/score, accumulated with HIP events on the ctx stream since the last
+ * reset (profiling on costs one event pair per launch).  names/ms/launches point into library storage. */
+int gasm_profile_enable(gasm_ctx* ctx, int on);
+int gasm_profile_reset(gasm_ctx* ctx);
+int gasm_profile_read(gasm_ctx* ctx, int* n, const char* const** names, const double** ms, const uint64_t** launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GASM_H */

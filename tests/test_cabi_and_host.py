@@ -1,0 +1,91 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/gasm.h declares; host-side algorithms of
+the boundary (shuffle, greedy merge, Levenshtein, table normalisation) agree with the oracle.  No GPU needed."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import genomeassembler_dev_amd as ga
+from genomeassembler_dev_amd import _lib, qtable
+from oracle import orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "gasm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gasm_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) > 40
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libgasm.so does not export {name}"
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    assert b"gfx950" in L.gasm_version()
+
+
+def test_no_device_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(ga.GasmError) as e:
+        ga.Context(0)
+    assert "GASM_ERR_NO_DEVICE" in str(e.value)
+
+
+def test_table_normalisation_matches_oracle(qtable):
+    _, prob = qtable
+    mine = ga.qtable.load_normalised()
+    assert np.array_equal(mine, prob)
+    raw = ga.qtable.load_raw().copy()
+    raw[[3, 20, 5000]] = np.nan
+    assert np.array_equal(ga.qtable.normalise(raw), orc.normalise_tables(raw, [16, 256, 4096, 65536]))
+
+
+@pytest.mark.parametrize("infix", [False, True])
+def test_levenshtein_matches_oracle(infix):
+    rng = np.random.default_rng(5)
+    for n, m in [(1, 1), (5, 9), (63, 64), (64, 64), (65, 130), (200, 777), (700, 150), (1000, 1000)]:
+        q = "".join(rng.choice(list("ACGT"), n))
+        t = "".join(rng.choice(list("ACGT"), m))
+        if n > 20:  # make it a noisy copy so distances are not trivially large
+            t = (q[: n // 2] + t[: m // 3] + q[n // 2:])[:m] if m >= n else t
+        assert ga.levenshtein(q, t, infix) == orc.levenshtein(q, t, infix), (n, m)
+    assert ga.levenshtein("", "ACGT", infix) == 0 and ga.levenshtein("ACGT", "", infix) == 0
+
+
+def _random_contig_set(rng, n, k):
+    g = "".join(rng.choice(list("ACGT"), 400))
+    cs = set()
+    for _ in range(n):
+        a = int(rng.integers(0, 300))
+        cs.add(g[a:a + int(rng.integers(k, 80))])
+    return sorted(cs)
+
+
+def test_shuffle_and_assemble_match_oracle():
+    rng = np.random.default_rng(11)
+    for k in (5, 9, 15):
+        contigs = _random_contig_set(rng, 9, k)
+        rows = 300
+        # velvet form: the oracle shuffles strings, the library shuffles indices — same std::shuffle draws
+        assert ga.assemble_contigs_velvet(contigs, k, 1234, rows=rows) == orc.assemble_contigs_velvet(contigs, k, 1234, rows=rows)
+        # matrix form
+        m = np.stack([np.random.default_rng(i).permutation(len(contigs)) for i in range(50)]).astype(np.uint32)
+        assert ga.assemble_contigs(ga.ContigMatrix(contigs, m, k, None, None, 1), k) == orc.assemble_contigs(contigs, m, k)
+        # list-of-lists form (the reference's R shape)
+        assert ga.assemble_contigs([[contigs[j] for j in row] for row in m], k) == orc.assemble_contigs(contigs, m, k)
+
+
+def test_assemble_short_contig_raises_like_reference():
+    with pytest.raises(IndexError):
+        ga.assemble_contigs_velvet(["ACG", "TTTTTTTT"], 6, 1, rows=3)
+    with pytest.raises(IndexError):
+        orc.assemble_contigs_velvet(["ACG", "TTTTTTTT"], 6, 1, rows=3)
+
+
+def test_get_kmers_from_reads_matches_oracle():
+    reads = ["ACGTACGTAC", "TTTT", "ACG", "GATTACAGATTACA"]
+    for k in (3, 4, 5):
+        assert ga.get_kmers_from_reads(reads, k) == orc.kmers_from_reads(reads, k)

@@ -1,0 +1,246 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+Bit-exact: distinct k-mers + multiplicities, edge lists, contigs, shuffle matrix, scaffolds, kmer_breaks, Levenshtein.
+FP64 scores: within 1e-9 absolute (north-star tolerance; the reference sums in hash-iteration order)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import genomeassembler_dev_amd as ga
+from genomeassembler_dev_amd import qtable, synth
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_survey_toy.json")))
+
+
+def _strs(a):
+    return [r.tobytes().decode() for r in a]
+
+
+def _check_scores(mine, ref, with_lev=True):
+    assert mine["sequence_len"].tolist() == ref["sequence_len"].tolist()
+    assert mine["kmer_breaks"].tolist() == ref["kmer_breaks"].tolist()
+    for key in ("bp_score", "bp_score_norm_by_break_freqs", "bp_score_norm_by_len"):
+        a, b = np.asarray(mine[key]), np.asarray(ref[key])
+        assert np.array_equal(np.isnan(a), np.isnan(b)), key
+        ok = ~np.isnan(a)
+        assert np.abs(a[ok] - b[ok]).max(initial=0.0) < TOL, key
+    if with_lev:
+        assert mine["lev_dist_vs_true"].tolist() == ref["lev_dist_vs_true"].tolist()
+
+
+# ------------------------------------------------------------------------------------------------ golden vector
+def test_survey_known_answer_vector(qtable):
+    keys, prob = qtable
+    g = G["genome"]
+    reads = [g[s:s + G["read_len"]] for s in G["read_starts"]]
+    km = ga.get_kmers_from_reads(reads, G["dbg_kmer"])
+    m = ga.get_contigs(km, G["dbg_kmer"], G["seed"])
+    assert m.contigs == G["contigs"]
+    assert m.row(0) == G["shuffle_row0"]
+    sc = ga.assemble_contigs(m, G["dbg_kmer"])
+    assert [len(s) for s in sc] == G["scaffold_lens"] and sc[0] == g
+    b = ga.calc_breakscore(sc, reads, g, G["break_kmer"], keys, prob)
+    assert b["kmer_breaks"].tolist() == G["kmer_breaks"]
+    assert b["lev_dist_vs_true"].tolist() == G["lev_dist_vs_true"]
+    assert abs(b["bp_score"][0] - G["bp_score_0"]) < TOL
+    assert abs(b["bp_score_norm_by_break_freqs"][0] - G["bp_score_norm_by_break_freqs_0"]) < TOL
+    assert abs(b["bp_score_norm_by_len"][0] - G["bp_score_norm_by_len_0"]) < TOL
+    assert list(b["path_freq"].shape) == G["path_freq_shape"]
+    assert int((b["path_freq"][0] > 0).sum()) == G["path_freq_nonzeros_0"]
+
+
+# ------------------------------------------------------------------------------------------------ get_contigs
+# the reference's own operating points (scripts/02_Real_vs_rand_prob_own.R:21-31): L=1000, coverage 40
+@pytest.mark.parametrize("read_len,k", [(12, 9), (14, 9), (16, 13), (18, 15), (20, 15), (25, 15), (40, 15)])
+def test_get_contigs_reference_operating_points(read_len, k):
+    g = synth.make_segment(1000 + read_len, 1000, planted=False)
+    reads = _strs(synth.simulate_reads(g, read_len, 40, 5 + k))
+    km = ga.get_kmers_from_reads(reads, k)
+    ref = orc.get_contigs(km, k, 1234)
+    m = ga.get_contigs(km, k, 1234)
+    assert m.contigs == ref["contigs"]
+    assert np.array_equal(m.perm, ref["perm"])
+    assert m.distinct_kmers() == ref["distinct"]
+    assert m.distinct_mult.tolist() == ref["counts"].tolist()
+    # distinct k-mers are the distinct edges: (prefix, suffix) lists must agree too
+    assert [d[:-1] for d in m.distinct_kmers()] == ref["edge_prefix"]
+    assert [d[1:] for d in m.distinct_kmers()] == ref["edge_suffix"]
+    assert ga.assemble_contigs(m, k) == orc.assemble_contigs(ref["contigs"], ref["perm"], k)
+
+
+@pytest.mark.parametrize("k", [2, 3, 5, 11, 21, 31])
+def test_get_contigs_k_range_with_repeats(k):
+    g = synth.make_segment(7 + k, 6000, n_short=6, short_len=120, n_long=2, long_len=500, tandem_len=200, planted=True)
+    reads = _strs(synth.simulate_reads(g, max(k + 9, 40), 15, 3))
+    km = ga.get_kmers_from_reads(reads, k)
+    ref = orc.get_contigs(km, k, 7, rows=20)
+    m = ga.get_contigs(km, k, 7, matrix_rows=20)
+    assert m.contigs == ref["contigs"]
+    assert np.array_equal(m.perm, ref["perm"])
+    assert m.distinct_kmers() == ref["distinct"] and m.distinct_mult.tolist() == ref["counts"].tolist()
+
+
+def test_get_contigs_edge_cases():
+    # isolated cycle: every node has in = out = 1 -> no contig
+    cyc = "ACGTTGCA"
+    km = [(cyc + cyc)[i:i + 4] for i in range(len(cyc))]
+    assert ga.get_contigs(km, 4, 1, matrix_rows=3).contigs == orc.get_contigs(km, 4, 1, rows=3)["contigs"] == []
+    # pure linear chain: one contig, source -> sink
+    lin = "ACGGTCATTGCAAGTC"
+    km = [lin[i:i + 5] for i in range(len(lin) - 4)]
+    assert ga.get_contigs(km, 5, 1, matrix_rows=3).contigs == orc.get_contigs(km, 5, 1, rows=3)["contigs"] == [lin]
+    # a single k-mer, duplicated
+    assert ga.get_contigs(["ACGTA"] * 7, 5, 1, matrix_rows=2).contigs == ["ACGTA"]
+    # homopolymer self-loop
+    km = ["AAAA", "AAAA", "AAAC"]
+    assert ga.get_contigs(km, 4, 1, matrix_rows=2).contigs == orc.get_contigs(km, 4, 1, rows=2)["contigs"]
+    # nothing
+    m = ga.get_contigs([], 5, 1, matrix_rows=4)
+    assert m.contigs == [] and m.perm.shape == (4, 0)
+
+
+def test_non_acgt_is_rejected():
+    with pytest.raises(ga.GasmError) as e:
+        ga.get_contigs(["ACGTN"], 5, 1)
+    assert "GASM_ERR_NON_ACGT" in str(e.value)
+    with pytest.raises(ga.GasmError):
+        ga.get_contigs(["acgta"], 5, 1)
+
+
+# ------------------------------------------------------------------------------------------------ batches
+@pytest.mark.parametrize("n_seg,L,rl,cov,k", [(4, 5000, 100, 20, 21), (3, 8000, 150, 25, 31), (5, 1500, 40, 30, 15)])
+def test_batch_build_and_score_against_oracle(qtable, n_seg, L, rl, cov, k):
+    keys, prob = qtable
+    reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, cov, seed0=900 + k, planted=True)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    b.build(k).score(8, prob)
+    assert b.total_kmers() == reads.shape[0] * (rl - k + 1)
+    contigs, sc = b.contigs(), b.scores()
+    for s in range(n_seg):
+        rs = _strs(reads[int(seg_off[s]):int(seg_off[s + 1])])
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+        assert contigs[s] == ref["contigs"]
+        dk, dm = b.distinct_kmers(s)
+        assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist()
+        o = orc.calc_breakscore(contigs[s], rs, genomes[s].tobytes().decode(), 8, keys, prob, with_lev=False, with_freq=False)
+        a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+        mine = {kk: v[a:e] for kk, v in sc.items() if kk != "seg_contig_off"}
+        _check_scores(mine, o, with_lev=False)
+    b.close()
+
+
+def test_batch_ragged_reads_and_empty_segment():
+    rng = np.random.default_rng(3)
+    g = _strs(synth.make_segment(5, 3000, planted=False)[None, :])[0]
+    seg0 = [g[a:a + int(rng.integers(10, 90))] for a in rng.integers(0, 2900, 400)]
+    segs = [seg0, [], ["ACGTACGTTGCA", "ACG"], seg0[:50]]
+    b = ga.SegmentBatch.from_strings(segs)
+    b.build(11)
+    contigs = b.contigs()
+    for s, rs in enumerate(segs):
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, 11), 11, 1, rows=1)
+        assert contigs[s] == ref["contigs"]
+        dk, dm = b.distinct_kmers(s)
+        assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist()
+    b.close()
+
+
+# ------------------------------------------------------------------------------------------------ calc_breakscore
+def _score_case(seed, L=1200, rl=20, cov=40, k=15):
+    g = synth.make_segment(seed, L, n_short=3, short_len=60, n_long=1, long_len=150, tandem_len=60, planted=True)
+    reads = _strs(synth.simulate_reads(g, rl, cov, seed + 1))
+    km = ga.get_kmers_from_reads(reads, k)
+    m = ga.get_contigs(km, k, 1234, matrix_rows=200)
+    return g.tobytes().decode(), reads, ga.assemble_contigs(m, k)
+
+
+def test_calc_breakscore_own_variant(qtable):
+    keys, prob = qtable
+    for seed in (21, 22):
+        truth, reads, paths = _score_case(seed)
+        mine = ga.calc_breakscore(paths, reads, truth, 8, keys, prob)
+        ref = orc.calc_breakscore(paths, reads, truth, 8, keys, prob)
+        _check_scores(mine, ref)
+        for i in range(len(paths)):
+            a, b = mine["path_freq"][i], ref["path_freq_by_input"][i]
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            assert np.abs(np.nan_to_num(a) - np.nan_to_num(b)).max() == 0.0
+            # the reference's own order is hash order: as a multiset it must agree as well
+            assert np.array_equal(np.sort(np.nan_to_num(a)), np.sort(np.nan_to_num(ref["path_freq"][i])))
+
+
+def test_calc_breakscore_velvet_variant(qtable):
+    keys, prob = qtable
+    truth, reads, paths = _score_case(31)
+    paths = paths + [truth[100:400], truth[:50]]
+    mine = ga.calc_breakscore(paths, reads, truth, 8, keys, prob, variant="velvet")
+    ref = orc.calc_breakscore(paths, reads, truth, 8, keys, prob, velvet=True)
+    _check_scores(mine, ref)
+    assert mine["path_prob_dist_startpos"].tolist() == ref["path_prob_dist_startpos"].tolist()
+    for a, b in zip(mine["path_prob_dist"], ref["path_prob_dist"]):
+        assert np.array_equal(a, b)
+
+
+def test_calc_breakscore_window_edges_and_duplicates(qtable):
+    """reads matching at path positions 0..5 (window widths 8,2,4,6,8,8), duplicate reads, a read occurring twice in
+    a path (first occurrence only), reads matching nothing, random ('uniform') table."""
+    keys, _ = qtable
+    prob = qtable_uniform = ga.qtable.uniform()
+    path = "ACGTTGCATGCAAGTCCGATAGGCTTACGATCGGATCCGTA"
+    rep = "GGATTACAGGATTACATTTT"
+    paths = [path, rep + "CC" + rep, path[3:30]]
+    reads = [path[i:i + 9] for i in range(6)] + [path[2:11]] * 3 + ["GATTACA", "TTTTTTTTT", path[-9:]]
+    mine = ga.calc_breakscore(paths, reads, path, 8, keys, prob)
+    ref = orc.calc_breakscore(paths, reads, path, 8, keys, prob)
+    _check_scores(mine, ref)
+    assert mine["kmer_breaks"][0] == 6 + 3 + 1
+    del qtable_uniform
+    # nothing matches anywhere: total 0 -> NaN frequencies like the reference's 0/0
+    mine = ga.calc_breakscore(["ACGTACGTACGT"], ["GGGGGGGGG"], "ACGT", 8, keys, prob)
+    ref = orc.calc_breakscore(["ACGTACGTACGT"], ["GGGGGGGGG"], "ACGT", 8, keys, prob)
+    _check_scores(mine, ref)
+    assert np.isnan(mine["path_freq"]).all()
+
+
+# ------------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_segment_properties(qtable):
+    """BASELINE config 2 shape (50 kb, 100 bp, 50x, k=31) without the oracle: size-independent properties."""
+    _, prob = qtable
+    k, rl = 31, 100
+    reads, seg_off, genomes = synth.make_batch(2, 50000, rl, 50, seed0=4242, planted=True)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    b.build(k, genome_len_hint=50000).score(8, prob)
+    seg, keys_, mult, w = b.distinct()
+    sc = b.scores()
+    for s in range(2):
+        a, e = int(seg[s]), int(seg[s + 1])
+        ks = keys_[a:e]
+        assert (np.diff(ks.astype(object)) > 0).all()                      # sorted, distinct
+        assert int(mult[a:e].sum()) == (int(seg_off[s + 1]) - int(seg_off[s])) * (rl - k + 1)   # every k-mer counted once
+        cs = b.contigs(s)
+        assert cs == sorted(set(cs))                                       # canonical order
+        gs = genomes[s].tobytes().decode()
+        # every contig is a walk in the graph of the reads: all its k-mers are distinct k-mers of the segment
+        dk = set(b.distinct_kmers(s)[0])
+        tot = 0
+        for c in cs:
+            assert len(c) >= k
+            for i in range(len(c) - k + 1):
+                assert c[i:i + k] in dk
+            tot += len(c) - k + 1
+        assert tot <= len(dk)                                              # edge-disjoint chains
+        # error-free reads: each read lies inside the genome, so at full coverage the contigs tile it
+        assert sum(1 for c in cs if c in gs) >= 1
+        ca, ce = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+        assert (sc["kmer_breaks"][ca:ce] >= 0).all() and sc["kmer_breaks"][ca:ce].sum() > 0
+        assert np.allclose(sc["bp_score_norm_by_len"][ca:ce], sc["bp_score"][ca:ce] / sc["sequence_len"][ca:ce], rtol=0, atol=1e-18)
+    # idempotence: a second build+score of the same batch gives bit-identical scores (fixed summation order)
+    b.build(k, genome_len_hint=50000).score(8, prob)
+    sc2 = b.scores()
+    for key in ("bp_score", "bp_score_norm_by_break_freqs", "kmer_breaks"):
+        assert np.array_equal(sc[key], sc2[key])
+    b.close()
