@@ -73,6 +73,7 @@ SYMBOLS = {
     "gasm_batch_fetch_contigs": (_int, [_vp, _PP, _PP, _PP]),
     "gasm_batch_fetch_scores": (_int, [_vp, _PP, _PP, _PP, _PP, _PP]),
     "gasm_profile_enable": (_int, [_vp, _int]),
+    "gasm_profile_filter": (_int, [_vp, C.c_char_p]),
     "gasm_profile_reset": (_int, [_vp]),
     "gasm_profile_read": (_int, [_vp, C.POINTER(_int), _PP, _PP, _PP]),
 }
@@ -118,7 +119,9 @@ class Context:
     def stream(self):
         return lib().gasm_ctx_stream(self.h)
 
-    def profile(self, on=True):
+    def profile(self, on=True, only=None):
+        """HIP-event timing per kernel launch; `only` = iterable of kernel names to restrict it to"""
+        check(lib().gasm_profile_filter(self.h, ",".join(only).encode() if only else None))
         check(lib().gasm_profile_enable(self.h, int(on)))
 
     def profile_reset(self):

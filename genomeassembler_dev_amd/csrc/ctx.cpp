@@ -122,6 +122,21 @@ extern "C" int gasm_profile_enable(gasm_ctx* c, int on) {
     return GASM_OK;
 }
 
+extern "C" int gasm_profile_filter(gasm_ctx* c, const char* names) {
+    if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
+    c->prof_only.clear();
+    if (!names) return GASM_OK;
+    std::string cur;
+    for (const char* p = names;; ++p) {
+        if (*p == ',' || *p == 0) {
+            if (!cur.empty()) c->prof_only.push_back(cur);
+            cur.clear();
+            if (*p == 0) break;
+        } else cur.push_back(*p);
+    }
+    return GASM_OK;
+}
+
 extern "C" int gasm_profile_reset(gasm_ctx* c) {
     if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
     GCHK(c->prof_collect());

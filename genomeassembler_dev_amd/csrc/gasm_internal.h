@@ -75,6 +75,13 @@ struct gasm_ctx {
     size_t h_pin_words = 0;
     // profiling
     bool prof = false;
+    std::vector<std::string> prof_only;   // empty = every kernel
+    bool prof_wants(const char* name) const {
+        if (!prof) return false;
+        if (prof_only.empty()) return true;
+        for (auto& s : prof_only) if (s == name) return true;
+        return false;
+    }
     std::vector<ProfStage> stages;
     std::map<std::string, int> stage_ix;
     struct Pending { int stage; hipEvent_t a, b; };
@@ -96,9 +103,10 @@ struct gasm_ctx {
     do {                                                                                     \
         hipEvent_t _a = nullptr, _b = nullptr;                                               \
         int _st = -1;                                                                        \
-        if ((ctx)->prof) (ctx)->prof_begin(name, &_a, &_b, &_st);                            \
+        const bool _p = (ctx)->prof_wants(name);                                             \
+        if (_p) (ctx)->prof_begin(name, &_a, &_b, &_st);                                     \
         hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__);            \
-        if ((ctx)->prof) (ctx)->prof_end(_st, _a, _b);                                       \
+        if (_p) (ctx)->prof_end(_st, _a, _b);                                                \
         HIPCHK(hipGetLastError());                                                           \
     } while (0)
 

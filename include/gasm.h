@@ -174,6 +174,8 @@ int gasm_batch_fetch_scores(gasm_batch* b, const double** bp_score, const double
 /* Per-kernel device time of the stages of build/score, accumulated with HIP events on the ctx stream since the last
  * reset (profiling on costs one event pair per launch).  names/ms/launches point into library storage. */
 int gasm_profile_enable(gasm_ctx* ctx, int on);
+/* restrict profiling to the comma-separated kernel names (NULL or "" = every kernel) */
+int gasm_profile_filter(gasm_ctx* ctx, const char* names);
 int gasm_profile_reset(gasm_ctx* ctx);
 int gasm_profile_read(gasm_ctx* ctx, int* n, const char* const** names, const double** ms, const uint64_t** launches);
 

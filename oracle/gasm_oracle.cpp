@@ -490,6 +490,24 @@ uint64_t orc_time_get_contigs(const char* kd, const uint64_t* koff, uint64_t nk,
     return contigs.size() + (M.empty() ? 0 : 0);
 }
 
+// timing entry for bench.py's cpu_baseline leg: what one GPU step does for one segment, the reference's way —
+// k-mers of the reads (lib/DeNovoAssembler.R:109-130), contigs (lib/DeNovoAssembler.cpp:91-192, no shuffle), then
+// calc_breakscore of those contigs against the reads (lib/DeNovoAssembler.cpp:325-426, no Levenshtein).
+// Returns the number of k-mers processed; *checksum gets sum(kmer_breaks) so the work cannot be optimised away.
+uint64_t orc_time_build_score(const char* rd, const uint64_t* roff, uint64_t nr, int k, int kmer, const char* kd,
+                              const uint64_t* koff, uint64_t nk, const double* prob, uint64_t* checksum) {
+    orc::StrVec reads = unpack(rd, roff, nr);
+    orc::StrVec km = orc::kmers_from_reads(reads, k);
+    orc::StrVec contigs = orc::dbg_contigs(km, k, nullptr);
+    orc::StrVec bpk = unpack(kd, koff, nk);
+    std::vector<double> bpp(prob, prob + nk);
+    orc::BreakScores R = orc::calc_breakscore(contigs, reads, std::string(), kmer, bpk, bpp, false, false);
+    uint64_t cs = 0;
+    for (int v : R.kmer_breaks) cs += (uint64_t)v;
+    *checksum = cs + contigs.size();
+    return km.size();
+}
+
 // tags: 1 scaffolds.  matrix given as `rows` permutations (u32 indices) of `contigs`.
 unsigned char* orc_assemble_matrix(const char* cd, const uint64_t* coff, uint64_t nc, const uint32_t* perm,
                                    uint64_t rows, int k, uint64_t* nbytes, int* err) {

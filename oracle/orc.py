@@ -117,6 +117,21 @@ def time_get_contigs(read_kmers_buf, off, nk, dbg_kmer, seed, rows=10000):
                                       C.c_int(rows))
 
 
+def time_build_score(reads, k, kmer, bp_kmer, bp_prob):
+    """cpu_baseline leg of bench.py: k-mers -> contigs -> scores of one segment, single thread.  Returns (#k-mers, s)."""
+    import time
+    rb, ro = _pack(reads)
+    kb, ko = _pack(bp_kmer)
+    prob = np.ascontiguousarray(bp_prob, dtype=np.float64)
+    cs = C.c_uint64()
+    f = lib().orc_time_build_score
+    f.restype = C.c_uint64
+    t0 = time.perf_counter()
+    n = f(rb, _p(ro), C.c_uint64(len(reads)), C.c_int(k), C.c_int(kmer), kb, _p(ko), C.c_uint64(len(bp_kmer)), _p(prob),
+          C.byref(cs))
+    return int(n), time.perf_counter() - t0
+
+
 def assemble_contigs(contigs, perm, dbg_kmer):
     """Restates assemble_contigs(contig_matrix, dbg_kmer) (lib/DeNovoAssembler.cpp:215-305); the matrix is given as
     `perm` (rows × len(contigs) indices)."""
