@@ -178,7 +178,7 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
     int st = rd.upload(ctx, reads ? reads : &empty, read_off, n_reads, 0, seg_off, 1);
     if (st == GASM_OK) st = dp.upload_ascii(ctx, paths ? paths : &empty, path_off, (u32)n_paths);
     if (st == GASM_OK) st = tb.set(ctx, bp_kmer, bp_off, n_table, bp_prob);
-    if (st == GASM_OK) st = pipeline_score_launch(ctx, rd, dp, kmer, tb, !velvet && (flags & GASM_WANT_FREQ), velvet, ss);
+    if (st == GASM_OK) st = pipeline_score_launch(ctx, rd, dp, kmer, tb, !velvet && (flags & GASM_WANT_FREQ), velvet, ss, nullptr);
     if (st == GASM_OK) st = pipeline_score_fetch(ctx, ss);
     gasm_scores* s = nullptr;
     if (st == GASM_OK) {
@@ -286,7 +286,7 @@ int gasm_batch_score(gasm_batch* b, int kmer, const double* table) {
         GCHK(pipeline_contig_paths(b->ctx, b->rd, b->bs, b->dp));
         b->paths_ready = true;
     }
-    return pipeline_score_launch(b->ctx, b->rd, b->dp, kmer, b->tb, false, false, b->ss);
+    return pipeline_score_launch(b->ctx, b->rd, b->dp, kmer, b->tb, false, false, b->ss, &b->bs);
     API_GUARD_END
 }
 

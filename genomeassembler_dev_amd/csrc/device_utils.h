@@ -11,6 +11,7 @@ typedef uint8_t u8;
 #define GASM_WG 256                    // threads per workgroup of the streaming kernels (4 waves)
 #define GASM_EMPTY64 0xFFFFFFFFFFFFFFFFull
 #define GASM_NONE32 0xFFFFFFFFu
+#define GASM_LINK_DONE 0x80000000ull   // link word: ancestor << 32 | done << 31 | distance
 
 // ----------------------------------------------------------------------------------------------------------------
 // Packed base streams.  Base j of a stream lives in 64-bit word j>>5 at bit 62-2*(j&31) (first base most

@@ -32,21 +32,27 @@ struct PathSet {
 };
 
 #define GASM_KT 16          // k-mers per thread and round of k_bucket_scatter
-#define GASM_TBL 4096       // slots of the LDS de-duplication table
-#define GASM_TBL_LIMIT 2816 // distinct keys one bucket may hold before the host re-partitions
+#define GASM_TBL 4096       // slots of the large LDS de-duplication table (the small one has 2048)
+#define GASM_TBL_LIMIT 2816 // distinct keys one bucket may hold (11/16 of the table) before the host re-partitions
 
 // ---- kernels_build.hip
 __global__ void k_pack_ascii(const u8* ascii, u64 nbases, u64* words, u64 nwords, u32* err);
-__global__ void k_bucket_hist(ReadSet rs, int k, int bbits, u32 g, u32 n_tiles, u32* hist);
+__global__ void k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 n_tiles, u32* tcnt);
+__global__ void k_tile_scan(ReadSet rs, int bbits, u32* tcnt, u32* hist);
 template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
 __global__ void k_copy_u64(const u64* a, u64* b, u32 n);
-__global__ void k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 n_tiles, u64* cursor, u64* keys);
-__global__ void k_bucket_dedup(u64* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow);
+template <int RT_T>
+__global__ void k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles, const u64* bstart,
+                                 const u32* toff, u64* keys);
+#define GASM_RT_MAX 16      // rounds (read groups x offset rounds) one scatter tile may hold
+template <int TBL>
+__global__ void k_bucket_dedup(u64* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, int low_bits);
 __global__ void k_bucket_gather(const u64* keys, const u32* mult, const u64* bstart, const u32* dstart, u64* dk_key,
                                 u32* dk_cnt);
 __global__ void k_node_flags(GraphView gv, u8* eflag);
 __global__ void k_edge_next(GraphView gv, const u8* eflag, u32* nxt, u64* link);
-__global__ void k_link_jump(const u8* eflag, u64* link, u32 n_edges);
+__global__ void k_link_jump(u64* link, u32 n_edges);
+__global__ void k_link_rank_seg(GraphView gv, u64* link, int max_rounds);
 __global__ void k_chain_len(const u8* eflag, const u32* nxt, const u64* link, u32* clen, u32 n_edges);
 __global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u32* e_cid, u64* e_coff, u32* seg_ncontig,
                               u64* seg_cbases);
@@ -61,9 +67,10 @@ struct SeedTable {
     const u64* tbl_off;   // n_segments+1 slot offsets; every segment's table size is a power of two
 };
 __global__ void k_seed_insert(PathSet ps, SeedTable st, const u64* seg_base_off, int w);
-__global__ void k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, u32* poscnt,
-                             u32* total);
-__global__ void k_path_reduce(PathSet ps, const u32* poscnt, const u32* total, const double* dprob, int kmer,
+__global__ void k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, u32* poscnt);
+__global__ void k_read_match_graph(ReadSet rs, GraphView gv, const u8* eflag, const u64* link, const u32* e_cid, PathSet ps,
+                                   u32* poscnt);
+__global__ void k_path_reduce(PathSet ps, const u32* poscnt, const u32* extra, const double* dprob, int kmer,
                               double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,
                               int32_t* seq_len, u32 n_paths);
 __global__ void k_path_freq(PathSet ps, const u32* poscnt, const u32* total, const int32_t* drow, int kmer, u32 n_table,

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(GASM_WG) k_pack_ascii(const u8* __restrict__ a
         }
     }
     words[t] = w;
-    if (!ok) atomicOr(err, 1u);
+    if (!ok && err) atomicOr(err, 1u);
 }
 
 // ================================================================================================================
@@ -72,32 +72,85 @@ __device__ __forceinline__ void read_span(const ReadSet& rs, u64 r, u64* p0, u32
     else { const u64 a = rs.read_off[r]; *p0 = a; *len = (u32)(rs.read_off[r + 1] - a); }
 }
 
-// Per-(segment,bucket) k-mer histogram.  The bucket of a k-mer is its first `bbits` bits (bbits <= 2k, bbits <= 10),
-// i.e. buckets are key ranges: concatenating sorted buckets gives a sorted segment.
-__global__ void __launch_bounds__(GASM_WG) k_bucket_hist(ReadSet rs, int k, int bbits, u32 g, u32 n_tiles,
-                                                         u32* __restrict__ hist) {
+// Thread `lane` of the g threads that share a read takes GASM_KT consecutive k-mer starts per round:
+// offsets round*g*KT + lane*KT + [0, KT).  The 16 windows come out of three 64-bit words held in registers
+// (16 + 31 bases span at most three words), so a k-mer costs a funnel shift, not two loads.
+struct Roll3 { u64 w0, w1, w2; u32 s; };
+
+__device__ __forceinline__ Roll3 roll_load(const u64* __restrict__ w, u64 p) {
+    Roll3 r;
+    const u64 i = p >> 5;
+    r.w0 = w[i]; r.w1 = w[i + 1]; r.w2 = w[i + 2];
+    r.s = (u32)(p & 31) << 1;
+    return r;
+}
+// the 32 bases starting j bases after the load position (0 <= j < 32)
+__device__ __forceinline__ u64 roll_window(const Roll3& r, u32 j) {
+    const u32 ob = r.s + 2 * j;            // < 126
+    const bool hi = ob >= 64;
+    const u64 x = hi ? r.w1 : r.w0, y = hi ? r.w2 : r.w1;
+    const u32 o = ob & 63;
+    return (x << o) | ((y >> 1) >> (63 - o));
+}
+
+// Per-tile k-mer histogram over buckets: tcnt[tile * nb + b].  The bucket of a k-mer is its first `bbits` bits
+// (bbits <= 2(k-1), bbits <= 10), i.e. buckets are key ranges: concatenating sorted buckets gives a sorted segment.
+// A tile is `tr` groups of GASM_WG/g reads (tile_decode is given ipt*tr).
+__global__ void __launch_bounds__(GASM_WG) k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 n_tiles,
+                                                       u32* __restrict__ tcnt) {
     extern __shared__ u32 s_h[];
     const u32 nb = 1u << bbits, ipt = GASM_WG / g;
     const u32 item = threadIdx.x / g, lane = threadIdx.x % g;
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         for (u32 b = threadIdx.x; b < nb; b += GASM_WG) s_h[b] = 0;
         __syncthreads();
-        const TileInfo ti = tile_decode(rs, tile, ipt);
-        if (item < ti.nitems) {
+        const TileInfo ti = tile_decode(rs, tile, ipt * tr);
+        for (u32 t = 0; t < tr; ++t) {
+            const u32 it = t * ipt + item;
+            if (it >= ti.nitems) break;
             u64 p0; u32 len;
-            read_span(rs, ti.r0 + item, &p0, &len);
+            read_span(rs, ti.r0 + it, &p0, &len);
             const u32 nk = len >= (u32)k ? len - k + 1 : 0;
-            for (u32 off = lane; off < nk; off += g) {
-                const u32 bkt = bbits ? (u32)(window32(rs.words, p0 + off) >> (64 - bbits)) : 0u;
-                atomicAdd(&s_h[bkt], 1u);
+            for (u32 off0 = lane * GASM_KT; off0 < nk; off0 += g * GASM_KT) {
+                const Roll3 r = roll_load(rs.words, p0 + off0);
+#pragma unroll
+                for (u32 j = 0; j < GASM_KT; ++j) {
+                    if (off0 + j < nk) {
+                        const u32 bkt = bbits ? (u32)(roll_window(r, j) >> (64 - bbits)) : 0u;
+                        atomicAdd(&s_h[bkt], 1u);
+                    }
+                }
             }
         }
         __syncthreads();
-        for (u32 b = threadIdx.x; b < nb; b += GASM_WG) {
-            const u32 c = s_h[b];
-            if (c) atomicAdd(&hist[(u64)ti.seg * nb + b], c);
-        }
+        for (u32 b = threadIdx.x; b < nb; b += GASM_WG) tcnt[(u64)tile * nb + b] = s_h[b];
         __syncthreads();
+    }
+}
+
+// Per segment and bucket: running sum of the tile counts (in place: tcnt becomes each tile's offset inside its
+// (segment,bucket) range) and the bucket total hist[seg * nb + b].  One workgroup per segment, thread = bucket.
+__global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32* __restrict__ tcnt, u32* __restrict__ hist) {
+    const u32 nb = 1u << bbits, seg = blockIdx.x;
+    const u32 t0 = rs.seg_tile_start[seg], t1 = rs.seg_tile_start[seg + 1];
+    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) {
+        u32 run = 0;
+        u32 t = t0;
+        for (; t + 4 <= t1; t += 4) {
+            const u32 c0 = tcnt[(u64)t * nb + b], c1 = tcnt[(u64)(t + 1) * nb + b], c2 = tcnt[(u64)(t + 2) * nb + b],
+                      c3 = tcnt[(u64)(t + 3) * nb + b];
+            tcnt[(u64)t * nb + b] = run;
+            tcnt[(u64)(t + 1) * nb + b] = run + c0;
+            tcnt[(u64)(t + 2) * nb + b] = run + c0 + c1;
+            tcnt[(u64)(t + 3) * nb + b] = run + c0 + c1 + c2;
+            run += c0 + c1 + c2 + c3;
+        }
+        for (; t < t1; ++t) {
+            const u32 c = tcnt[(u64)t * nb + b];
+            tcnt[(u64)t * nb + b] = run;
+            run += c;
+        }
+        hist[(u64)seg * nb + b] = run;
     }
 }
 
@@ -126,177 +179,298 @@ __global__ void k_copy_u64(const u64* __restrict__ a, u64* __restrict__ b, u32 n
 
 // ================================================================================================================
 // Scatter: every k-mer of every read is written once, 8 bytes, into its (segment,bucket) range of `keys`.
-// Keys are binned in LDS first (rank by ds_add_rtn, one global atomic per workgroup and bucket to reserve the
-// output range), so the global stores of one bucket are consecutive.
-// LDS: KT*256 keys (8 B) + bucket ids (2 B) + 3 bucket arrays.
+// The output range of a (tile,bucket) is known beforehand: bstart[seg,bucket] + toff[tile,bucket]
+// (k_tile_hist/k_tile_scan), so there is no global atomic and the layout is deterministic.
+//
+// A tile is RT rounds (tr read groups x `orr` offset rounds) of up to 4096 k-mers.  Pass 1 counts every round's
+// k-mers per (round, wave, bucket) in LDS; ONE workgroup barrier; after it the four waves never meet again in this
+// tile: for each round a wave derives its slice of every bucket's range from the count cube, ranks its k-mers into
+// wave-private bins (ds_add_rtn), stages them bucket by bucket in its private LDS area and streams them out, so the
+// global stores of one bucket are consecutive.  The count cube and the tile bases are double buffered by tile parity so
+// a fast wave can start the next tile while a slow one finishes this one.
+// LDS: per wave KT*64 keys (8 B) + bucket ids (2 B) + nb*16; shared 2*RT*4*nb*4 + 2*nb*8  (54 272 B at nb = 64, RT = 4:
+// three workgroups per CU).
 // ================================================================================================================
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-__global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 n_tiles,
-                                                            u64* __restrict__ cursor, u64* __restrict__ keys) {
+template <int RT_T>   // rounds per tile known at compile time (4), or 0 = run-time value
+__global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles,
+                                                            const u64* __restrict__ bstart, const u32* __restrict__ toff,
+                                                            u64* __restrict__ keys) {
     extern __shared__ __align__(16) unsigned char s_raw[];
+    constexpr u32 WSTAGE = GASM_KT * 64;
+    const u32 RT = RT_T ? (u32)RT_T : tr * orr;
     const u32 nb = 1u << bbits, ipt = GASM_WG / g;
-    u64* s_key = reinterpret_cast<u64*>(s_raw);                        // GASM_KT*GASM_WG
-    u64* s_gbase = s_key + GASM_KT * GASM_WG;                          // nb
-    u32* s_cnt = reinterpret_cast<u32*>(s_gbase + nb);                 // nb
-    u32* s_off = s_cnt + nb;                                           // nb
-    u32* s_tmp = s_off + nb;                                           // 8 (+ max nk at [6])
-    u16* s_bkt = reinterpret_cast<u16*>(s_tmp + 8);                    // GASM_KT*GASM_WG
+    const u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    // carve LDS
+    u64* s_key_all = reinterpret_cast<u64*>(s_raw);                       // 4 * WSTAGE
+    u64* s_gbase_all = s_key_all + 4 * WSTAGE;                            // 2 * nb
+    u32* s_cube_all = reinterpret_cast<u32*>(s_gbase_all + 2 * nb);       // 2 * RT * 4 * nb
+    u32* s_off_all = s_cube_all + 2 * RT * 4 * nb;                        // 4 * nb
+    u32* s_cur_all = s_off_all + 4 * nb;                                  // 4 * nb
+    u32* s_adv_all = s_cur_all + 4 * nb;                                  // 4 * nb
+    u32* s_wbase_all = s_adv_all + 4 * nb;                                // 4 * nb   (relative to the tile base)
+    u16* s_bkt_all = reinterpret_cast<u16*>(s_wbase_all + 4 * nb);        // 4 * WSTAGE
+    u64* s_key = s_key_all + wv * WSTAGE;
+    u32* s_wbase = s_wbase_all + wv * nb;
+    u32* s_off = s_off_all + wv * nb;
+    u32* s_cur = s_cur_all + wv * nb;
+    u32* s_adv = s_adv_all + wv * nb;
+    u16* s_bkt = s_bkt_all + wv * WSTAGE;
     const u32 item = threadIdx.x / g, lane = threadIdx.x % g;
     const int kshift = 64 - 2 * k;
+    u32 par = 0;
 
-    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const TileInfo ti = tile_decode(rs, tile, ipt);
-        u64 p0 = 0; u32 nk = 0;
-        if (item < ti.nitems) {
-            u32 len;
-            read_span(rs, ti.r0 + item, &p0, &len);
-            nk = len >= (u32)k ? len - k + 1 : 0;
-        }
-        if (threadIdx.x == 0) s_tmp[6] = 0;
-        for (u32 b = threadIdx.x; b < nb; b += GASM_WG) s_cnt[b] = 0;
-        __syncthreads();
-        if (lane == 0 && nk) atomicMax(&s_tmp[6], nk);
-        __syncthreads();
-        const u32 max_nk = s_tmp[6];
-        const u32 per_round = g * GASM_KT;
-        for (u32 r0 = 0; r0 < max_nk; r0 += per_round) {
-            u64 key[GASM_KT];
-            u32 meta[GASM_KT];  // bucket << 16 | rank   (rank < 4096)
-#pragma unroll
-            for (int j = 0; j < GASM_KT; ++j) {
-                const u32 off = r0 + j * g + lane;
-                meta[j] = GASM_NONE32;
-                if (off < nk) {
-                    const u64 wdw = window32(rs.words, p0 + off);
-                    key[j] = wdw >> kshift;
-                    const u32 bkt = bbits ? (u32)(wdw >> (64 - bbits)) : 0u;
-                    meta[j] = (bkt << 16) | atomicAdd(&s_cnt[bkt], 1u);
-                }
+    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
+        const TileInfo ti = tile_decode(rs, tile, ipt * tr);
+        u64* s_gbase = s_gbase_all + par * nb;
+        u32* s_cube = s_cube_all + par * RT * 4 * nb;      // [RT][4][nb]
+        for (u32 b = threadIdx.x; b < nb; b += GASM_WG) s_gbase[b] = bstart[(u64)ti.seg * nb + b] + toff[(u64)tile * nb + b];
+        for (u32 q = 0; q < RT; ++q)
+            for (u32 b = ln; b < nb; b += 64) s_cube[(q * 4 + wv) * nb + b] = 0;
+        wave_sync_lds();
+        // ---- pass 1: count every round (this wave's rows of the cube)
+        auto round_span = [&](u32 q, u64* p0, u32* nk, u32* off0) {
+            const u32 t = q / orr, o = q - t * orr;
+            const u32 it = t * ipt + item;
+            *nk = 0; *p0 = 0;
+            if (it < ti.nitems) {
+                u32 len;
+                read_span(rs, ti.r0 + it, p0, &len);
+                *nk = len >= (u32)k ? len - k + 1 : 0;
             }
-            __syncthreads();
-            // exclusive scan of the bucket counts; reserve the global ranges
-            {
-                const u32 per = nb > GASM_WG ? nb / GASM_WG : 1;
-                const u32 base = threadIdx.x * per;
-                u32 sum = 0;
-                for (u32 q = 0; q < per; ++q) if (base + q < nb) sum += s_cnt[base + q];
-                u32 tot;
-                u32 ex = block_excl_scan<GASM_WG>(sum, s_tmp, &tot);
-                for (u32 q = 0; q < per; ++q) {
-                    if (base + q < nb) {
-                        const u32 c = s_cnt[base + q];
-                        s_off[base + q] = ex;
-                        if (c) s_gbase[base + q] = atomicAdd(reinterpret_cast<unsigned long long*>(&cursor[(u64)ti.seg * nb + base + q]),
-                                                             (unsigned long long)c);
-                        ex += c;
+            *off0 = o * g * GASM_KT + lane * GASM_KT;
+        };
+#pragma unroll
+        for (u32 q = 0; q < (RT_T ? (u32)RT_T : RT); ++q) {
+            u64 p0; u32 nk, off0;
+            round_span(q, &p0, &nk, &off0);
+            if (off0 < nk) {
+                const Roll3 rl = roll_load(rs.words, p0 + off0);
+                u32* row = s_cube + (q * 4 + wv) * nb;
+#pragma unroll
+                for (u32 j = 0; j < GASM_KT; ++j) {
+                    if (off0 + j < nk) {
+                        const u32 bkt = bbits ? (u32)(roll_window(rl, j) >> (64 - bbits)) : 0u;
+                        atomicAdd(&row[bkt], 1u);
                     }
                 }
-                if (threadIdx.x == 0) s_tmp[7] = tot;
             }
-            __syncthreads();
+        }
+        __syncthreads();   // the count cube and the tile bases are complete
+        // ---- pass 2: place, round by round, every wave on its own
+        for (u32 b = ln; b < nb; b += 64) s_wbase[b] = 0;   // running offset behind the tile base: all earlier rounds
+        for (u32 q = 0; q < RT; ++q) {
+            u64 p0; u32 nk, off0;
+            round_span(q, &p0, &nk, &off0);
+            // this wave's slice of every bucket in this round + staging offsets
+            u32 carry = 0;
+            for (u32 b0 = 0; b0 < nb; b0 += 64) {
+                const u32 b = b0 + ln;
+                u32 c = 0, lower = 0, upper = 0;
+                if (b < nb) {
+                    const u32* rows = s_cube + q * 4 * nb + b;
+                    c = rows[wv * nb];
+                    for (u32 w2 = 0; w2 < 4; ++w2) { const u32 v = rows[w2 * nb]; if (w2 < wv) lower += v; else if (w2 > wv) upper += v; }
+                }
+                const u32 inc = wave_incl_scan(c);
+                if (b < nb) {
+                    s_off[b] = carry + inc - c;
+                    s_cur[b] = 0;
+                    s_wbase[b] += lower;                     // start of this wave's slice in this round
+                    s_adv[b] = c + upper;                    // to the next round: own count + the waves above
+                }
+                carry += __shfl(inc, 63, 64);
+            }
+            wave_sync_lds();
+            if (off0 < nk) {
+                const Roll3 rl = roll_load(rs.words, p0 + off0);
 #pragma unroll
-            for (int j = 0; j < GASM_KT; ++j) {
-                if (meta[j] != GASM_NONE32) {
-                    const u32 bkt = meta[j] >> 16;
-                    const u32 idx = s_off[bkt] + (meta[j] & 0xFFFFu);
-                    s_key[idx] = key[j];
-                    s_bkt[idx] = (u16)bkt;
+                for (u32 j = 0; j < GASM_KT; ++j) {
+                    if (off0 + j < nk) {
+                        const u64 wdw = roll_window(rl, j);
+                        const u32 bkt = bbits ? (u32)(wdw >> (64 - bbits)) : 0u;
+                        const u32 idx = s_off[bkt] + atomicAdd(&s_cur[bkt], 1u);
+                        s_key[idx] = wdw >> kshift;
+                        s_bkt[idx] = (u16)bkt;
+                    }
                 }
             }
-            __syncthreads();
-            const u32 total = s_tmp[7];
-            for (u32 i = threadIdx.x; i < total; i += GASM_WG) {
+            wave_sync_lds();
+            for (u32 i = ln; i < carry; i += 64) {
                 const u32 bkt = s_bkt[i];
-                keys[s_gbase[bkt] + (i - s_off[bkt])] = s_key[i];
+                keys[s_gbase[bkt] + s_wbase[bkt] + (i - s_off[bkt])] = s_key[i];
             }
-            __syncthreads();
-            for (u32 b = threadIdx.x; b < nb; b += GASM_WG) s_cnt[b] = 0;
-            __syncthreads();
+            wave_sync_lds();
+            for (u32 b = ln; b < nb; b += 64) s_wbase[b] += s_adv[b];
         }
     }
 }
+template __global__ void k_bucket_scatter<4>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, u64*);
+template __global__ void k_bucket_scatter<0>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, u64*);
 
 // ================================================================================================================
 // De-duplicate one bucket: stream its keys through an LDS open-addressing table (64-bit CAS on the key, 32-bit add on
-// the multiplicity), compact the table in place, bitonic-sort it, and write the sorted distinct keys and their
-// multiplicities back over the start of the bucket's own range.  A bucket with more than GASM_TBL_LIMIT distinct
-// keys raises *overflow (the host then re-partitions with more bucket bits).
+// the multiplicity), then order the distinct keys and write them and their multiplicities back over the start of the
+// bucket's own range.  Ordering: a counting sort on the bits below the bucket prefix (TBL/4 bins; the keys of a bucket
+// share the prefix, the next bits are close to uniform) puts every key into its bin's range, bins of more than one
+// key are finished by a per-bin insertion sort; if any bin is long (skewed keys) the workgroup falls back to a
+// bitonic sort.  A bucket with more than 11/16*TBL distinct keys raises *overflow (the host re-partitions).
 // ================================================================================================================
-
+template <int TBL>
 __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys, u32* __restrict__ mult,
                                                           const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
-                                                          u32* __restrict__ overflow) {
-    __shared__ u64 t_key[GASM_TBL];
-    __shared__ u32 t_cnt[GASM_TBL];
+                                                          u32* __restrict__ overflow, int low_bits) {
+    constexpr int LIMIT = TBL / 16 * 11;
+    constexpr int BINS = TBL / 4;
+    constexpr int SL = TBL / GASM_WG;
+    constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
+    static_assert(TBL == 4096 || TBL == 2048, "table size");
+    __shared__ u64 t_key[TBL];
+    __shared__ u32 t_cnt[TBL];
+    __shared__ u32 s_start[BINS];
+    __shared__ u32 s_cur[BINS];
     __shared__ u32 s_tmp[8];
     const u32 bucket = blockIdx.x;
     const u64 beg = bstart[bucket], end = bstart[bucket + 1];
     const u64 n = end - beg;
-    for (u32 i = threadIdx.x; i < GASM_TBL; i += GASM_WG) { t_key[i] = GASM_EMPTY64; t_cnt[i] = 0; }
-    if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; }  // [4] distinct so far, [5] overflow
+    for (u32 i = threadIdx.x; i < TBL; i += GASM_WG) { t_key[i] = GASM_EMPTY64; t_cnt[i] = 0; }
+    for (u32 i = threadIdx.x; i < BINS; i += GASM_WG) s_start[i] = 0;
+    if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }  // [4] distinct so far, [5] overflow, [6] longest bin
     __syncthreads();
-    for (u64 i = threadIdx.x; i < n; i += GASM_WG) {
-        const u64 key = keys[beg + i];
-        if (*reinterpret_cast<volatile u32*>(&s_tmp[4]) > GASM_TBL_LIMIT) { s_tmp[5] = 1; break; }
-        u32 h = hash64(key) >> (32 - 12);
-        while (true) {
-            const u64 cur = *reinterpret_cast<volatile u64*>(&t_key[h]);
-            if (cur == key) { atomicAdd(&t_cnt[h], 1u); break; }
+    // insert with a bounded probe sequence (a full table raises the overflow flag instead of spinning)
+    auto insert = [&](u64 key) {
+        u32 h = hash64(key) >> (32 - LOG_TBL);
+        for (u32 probe = 0; probe < TBL; ++probe) {
+            const u64 cur = __hip_atomic_load(&t_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (cur == key) { atomicAdd(&t_cnt[h], 1u); return; }
             if (cur == GASM_EMPTY64) {
                 const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&t_key[h]), (unsigned long long)GASM_EMPTY64,
                                           (unsigned long long)key);
-                if (old == GASM_EMPTY64) { atomicAdd(&s_tmp[4], 1u); atomicAdd(&t_cnt[h], 1u); break; }
-                if (old == key) { atomicAdd(&t_cnt[h], 1u); break; }
+                if (old == GASM_EMPTY64) { atomicAdd(&s_tmp[4], 1u); atomicAdd(&t_cnt[h], 1u); return; }
+                if (old == key) { atomicAdd(&t_cnt[h], 1u); return; }
             }
-            h = (h + 1) & (GASM_TBL - 1);
+            h = (h + 1) & (TBL - 1);
+        }
+        s_tmp[5] = 1;
+    };
+    // 16-byte loads, four in flight per thread (the loop is latency-bound otherwise): head/tail singles, pairs between
+    const u64 a0 = (beg + 1) & ~1ull;
+    if (threadIdx.x == 0 && a0 > beg && n) insert(keys[beg]);
+    const u64 first = a0 < end ? a0 : end;
+    const u64 npairs = (end - first) >> 1;
+    if (threadIdx.x == 1 && ((end - first) & 1)) insert(keys[end - 1]);
+    const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(keys + first);
+    for (u64 i = threadIdx.x; i < npairs; i += 4 * GASM_WG) {
+        ulonglong2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u64 j = i + (u64)q * GASM_WG;
+            v[q] = j < npairs ? kp[j] : make_ulonglong2(GASM_EMPTY64, GASM_EMPTY64);
+        }
+        if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { s_tmp[5] = 1; break; }
+        // first probes of all eight keys in flight together (one LDS round trip instead of eight); nearly every key
+        // is a repeat of one already in the table, so the hit path is the common one
+        u64 kx[8], cur[8];
+        u32 hx[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { kx[2 * q] = v[q].x; kx[2 * q + 1] = v[q].y; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            hx[q] = hash64(kx[q]) >> (32 - LOG_TBL);
+            cur[q] = __hip_atomic_load(&t_key[hx[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (kx[q] == GASM_EMPTY64) continue;
+            if (cur[q] == kx[q]) atomicAdd(&t_cnt[hx[q]], 1u);
+            else insert(kx[q]);
         }
     }
     __syncthreads();
-    if (s_tmp[5]) {
+    if (s_tmp[5] || s_tmp[4] > (u32)LIMIT) {
         if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[bucket] = 0; }
         return;
     }
-    // ---- compact in place: every thread pulls its 16 slots (stride 256: conflict-free) into registers
-    u64 rk[GASM_TBL / GASM_WG];
-    u32 rc[GASM_TBL / GASM_WG];
-    u32 mine = 0;
+    const u32 d = s_tmp[4];
+    // ---- every thread pulls its slots (stride 256: conflict-free) into registers and bins them
+    const int bshift = low_bits > (LOG_TBL - 2) ? low_bits - (LOG_TBL - 2) : 0;
+    u64 rk[SL];
+    u32 rc[SL];
 #pragma unroll
-    for (int q = 0; q < GASM_TBL / GASM_WG; ++q) {
+    for (int q = 0; q < SL; ++q) {
         rk[q] = t_key[q * GASM_WG + threadIdx.x];
         rc[q] = t_cnt[q * GASM_WG + threadIdx.x];
-        mine += rk[q] != GASM_EMPTY64;
+        if (rk[q] != GASM_EMPTY64) atomicAdd(&s_start[(u32)(rk[q] >> bshift) & (BINS - 1)], 1u);
     }
-    u32 d;
-    u32 pos = block_excl_scan<GASM_WG>(mine, s_tmp, &d);  // barriers inside: all reads are done before any write
+    __syncthreads();   // all table reads and all bin counts are done
+    {
+        constexpr int PER = BINS / GASM_WG;   // 4 or 2
+        u32 c[PER], sum = 0, mx = 0;
 #pragma unroll
-    for (int q = 0; q < GASM_TBL / GASM_WG; ++q) {
-        if (rk[q] != GASM_EMPTY64) { t_key[pos] = rk[q]; t_cnt[pos] = rc[q]; ++pos; }
+        for (int q = 0; q < PER; ++q) { c[q] = s_start[threadIdx.x * PER + q]; sum += c[q]; mx = c[q] > mx ? c[q] : mx; }
+        u32 tot;
+        u32 ex = block_excl_scan<GASM_WG>(sum, s_tmp, &tot);
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { s_start[threadIdx.x * PER + q] = ex; s_cur[threadIdx.x * PER + q] = ex; ex += c[q]; }
+        if (mx > 1) atomicMax(&s_tmp[6], mx);
     }
-    u32 p2 = 2;
-    while (p2 < d) p2 <<= 1;
     __syncthreads();
-    for (u32 i = d + threadIdx.x; i < p2; i += GASM_WG) { t_key[i] = GASM_EMPTY64; t_cnt[i] = 0; }
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+        if (rk[q] != GASM_EMPTY64) {
+            const u32 pos = atomicAdd(&s_cur[(u32)(rk[q] >> bshift) & (BINS - 1)], 1u);
+            t_key[pos] = rk[q];
+            t_cnt[pos] = rc[q];
+        }
+    }
     __syncthreads();
-    // ---- bitonic sort of p2 (key, multiplicity) pairs, ascending
-    for (u32 kk = 2; kk <= p2; kk <<= 1) {
-        for (u32 j = kk >> 1; j > 0; j >>= 1) {
-            for (u32 t = threadIdx.x; t < (p2 >> 1); t += GASM_WG) {
-                const u32 lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const u32 hi = lo | j;
-                const u64 a = t_key[lo], b = t_key[hi];
-                const bool up = (lo & kk) == 0;
-                if ((a > b) == up) {
-                    t_key[lo] = b; t_key[hi] = a;
-                    const u32 ca = t_cnt[lo], cb = t_cnt[hi];
-                    t_cnt[lo] = cb; t_cnt[hi] = ca;
-                }
+    const u32 longest = s_tmp[6];
+    if (longest <= 24) {
+        // per-bin insertion sort (bins of 0/1 keys need nothing)
+        for (u32 b = threadIdx.x; b < (u32)BINS; b += GASM_WG) {
+            const u32 lo = s_start[b], hi = s_cur[b];
+            for (u32 i = lo + 1; i < hi; ++i) {
+                const u64 kx = t_key[i];
+                const u32 cx = t_cnt[i];
+                u32 j = i;
+                while (j > lo && t_key[j - 1] > kx) { t_key[j] = t_key[j - 1]; t_cnt[j] = t_cnt[j - 1]; --j; }
+                t_key[j] = kx;
+                t_cnt[j] = cx;
             }
-            __syncthreads();
+        }
+        __syncthreads();
+    } else {
+        // skewed keys: bitonic sort of the compacted entries
+        u32 p2 = 2;
+        while (p2 < d) p2 <<= 1;
+        for (u32 i = d + threadIdx.x; i < p2; i += GASM_WG) { t_key[i] = GASM_EMPTY64; t_cnt[i] = 0; }
+        __syncthreads();
+        for (u32 kk = 2; kk <= p2; kk <<= 1) {
+            for (u32 j = kk >> 1; j > 0; j >>= 1) {
+                for (u32 t = threadIdx.x; t < (p2 >> 1); t += GASM_WG) {
+                    const u32 lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const u32 hi = lo | j;
+                    const u64 a = t_key[lo], b = t_key[hi];
+                    const bool up = (lo & kk) == 0;
+                    if ((a > b) == up) {
+                        t_key[lo] = b; t_key[hi] = a;
+                        const u32 ca = t_cnt[lo], cb = t_cnt[hi];
+                        t_cnt[lo] = cb; t_cnt[hi] = ca;
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     for (u32 i = threadIdx.x; i < d; i += GASM_WG) { keys[beg + i] = t_key[i]; mult[beg + i] = t_cnt[i]; }
     if (threadIdx.x == 0) bucket_d[bucket] = d;
 }
+template __global__ void k_bucket_dedup<4096>(u64*, u32*, const u64*, u32*, u32*, int);
+template __global__ void k_bucket_dedup<2048>(u64*, u32*, const u64*, u32*, u32*, int);
 
 // Gather the per-bucket distinct runs into the dense per-segment arrays.
 __global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const u64* __restrict__ keys, const u32* __restrict__ mult,
@@ -342,7 +516,8 @@ __global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u8* __rest
 }
 
 // Successor edge of every edge (GASM_NONE32 when the walk stops at its target), and the initial ancestor links:
-// link = ancestor << 32 | distance.  Heads are their own ancestor at distance 0.
+// link = ancestor << 32 | done << 31 | distance, done = "the ancestor is the head of the chain".  Heads are their own
+// ancestor at distance 0.  The done bit travels with the link, so pointer doubling needs one gather per round.
 __global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, const u8* __restrict__ eflag, u32* __restrict__ nxt,
                                                        u64* __restrict__ link) {
     const u32 seg = blockIdx.y;
@@ -362,21 +537,72 @@ __global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, const u8* _
     u32 n = GASM_NONE32;
     if (j < bhi && (gv.dk_key[j] >> 2) == v && !(eflag[j] & 1)) n = j;  // v has out-edges and is not branching
     nxt[i] = n;
-    if (n != GASM_NONE32) link[n] = ((u64)i << 32) | 1ull;
-    if (eflag[i] & 1) link[i] = (u64)i << 32;
+    const u64 me_head = (eflag[i] & 1) ? GASM_LINK_DONE : 0ull;
+    if (n != GASM_NONE32) link[n] = ((u64)i << 32) | me_head | 1ull;
+    if (me_head) link[i] = ((u64)i << 32) | GASM_LINK_DONE;
 }
 
 // One round of pointer doubling towards the head of the chain.  In place and asynchronous: a link is always a
-// consistent (ancestor, distance) pair because it is read and written as one 64-bit word.
-__global__ void __launch_bounds__(GASM_WG) k_link_jump(const u8* __restrict__ eflag, u64* __restrict__ link, u32 n_edges) {
+// consistent (ancestor, done, distance) triple because it is read and written as one 64-bit word.
+__global__ void __launch_bounds__(GASM_WG) k_link_jump(u64* __restrict__ link, u32 n_edges) {
     const u32 i = blockIdx.x * GASM_WG + threadIdx.x;
     if (i >= n_edges) return;
     const u64 l = link[i];
     const u32 a = (u32)(l >> 32);
-    if (a == GASM_NONE32 || (eflag[a] & 1)) return;
+    if (a == GASM_NONE32 || (l & GASM_LINK_DONE)) return;
     const u64 la = *reinterpret_cast<volatile const u64*>(&link[a]);
     if ((u32)(la >> 32) == GASM_NONE32) return;
-    link[i] = (la & 0xFFFFFFFF00000000ull) | (u64)((u32)l + (u32)la);
+    link[i] = (la & (0xFFFFFFFF00000000ull | GASM_LINK_DONE)) | (u64)(((u32)l + (u32)la) & 0x7FFFFFFFu);
+}
+
+// All rounds of pointer doubling for one segment inside one workgroup (no launch per round, early exit when every
+// chain has reached its head).  Links are read and written with relaxed workgroup-scope atomics so the
+// updates other waves of this workgroup made in the same round or the previous one are seen (workgroup scope: one
+// workgroup = one CU = one L1); a stale value would still be a valid (ancestor, distance) pair.  Members of isolated cycles never reach a head: they are dropped (ancestor =
+// none) once their distance exceeds the segment's edge count.
+#define GASM_RANK_BATCH 8
+__global__ void __launch_bounds__(1024) k_link_rank_seg(GraphView gv, u64* __restrict__ link, int max_rounds) {
+    __shared__ u32 s_active;
+    const u32 seg = blockIdx.x;
+    const u32 nb = 1u << gv.bbits;
+    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
+    const u32 n = hi - lo;
+    for (int r = 0; r < max_rounds; ++r) {
+        if (threadIdx.x == 0) s_active = 0;
+        __syncthreads();
+        bool any = false;
+        for (u32 base = lo + threadIdx.x; base < hi; base += 1024 * GASM_RANK_BATCH) {
+            u64 l[GASM_RANK_BATCH], la[GASM_RANK_BATCH];
+            bool act[GASM_RANK_BATCH];
+#pragma unroll
+            for (int q = 0; q < GASM_RANK_BATCH; ++q) {
+                const u32 i = base + q * 1024;
+                l[q] = i < hi ? __hip_atomic_load(&link[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < GASM_RANK_BATCH; ++q) {
+                const u32 a = (u32)(l[q] >> 32);
+                act[q] = a != GASM_NONE32 && !(l[q] & GASM_LINK_DONE);
+                la[q] = act[q] ? __hip_atomic_load(&link[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < GASM_RANK_BATCH; ++q) {
+                if (!act[q]) continue;
+                const u32 i = base + q * 1024;
+                const u32 a2 = (u32)(la[q] >> 32);
+                const u32 d = ((u32)l[q] & 0x7FFFFFFFu) + ((u32)la[q] & 0x7FFFFFFFu);
+                u64 nl;
+                if (a2 == GASM_NONE32 || d > n) nl = ~0ull;            // on an isolated cycle
+                else { nl = ((u64)a2 << 32) | (la[q] & GASM_LINK_DONE) | d; any = any || !(la[q] & GASM_LINK_DONE); }
+                __hip_atomic_store(&link[i], nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (any) s_active = 1;
+        __syncthreads();
+        const bool go = s_active != 0;
+        __syncthreads();
+        if (!go) break;
+    }
 }
 
 // Tail edges publish their chain's length (in edges) at the head.
@@ -387,8 +613,9 @@ __global__ void __launch_bounds__(GASM_WG) k_chain_len(const u8* __restrict__ ef
     if (nxt[i] != GASM_NONE32) return;
     const u64 l = link[i];
     const u32 a = (u32)(l >> 32);
-    if (a == GASM_NONE32 || !(eflag[a] & 1)) return;  // isolated cycle member: no contig starts there
-    clen[a] = (u32)l + 1;
+    if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;  // isolated cycle member: no contig starts there
+    clen[a] = ((u32)l & 0x7FFFFFFFu) + 1;
+    (void)eflag;
 }
 
 // Per segment: rank of every head among the segment's heads and the base offset of its contig inside the segment
@@ -441,11 +668,12 @@ __global__ void __launch_bounds__(GASM_WG) k_contig_emit(GraphView gv, const u8*
     if (i >= n_edges) return;
     const u64 l = link[i];
     const u32 a = (u32)(l >> 32);
-    if (a == GASM_NONE32 || !(eflag[a] & 1)) return;
+    if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;
+    (void)eflag;
     const u64 key = gv.dk_key[i];
     const u64 off = e_coff[a];
     const int k = gv.k;
-    out[off + (k - 1) + (u32)l] = "ACGT"[key & 3];
+    out[off + (k - 1) + ((u32)l & 0x7FFFFFFFu)] = "ACGT"[key & 3];
     if (a == i) {
         for (int j = 0; j < k - 1; ++j) out[off + j] = "ACGT"[(key >> (2 * (k - 1 - j))) & 3];
     }

@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(GASM_WG) k_seed_insert(PathSet ps, SeedTable s
 }
 
 __global__ void __launch_bounds__(GASM_WG) k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* __restrict__ seg_base_off,
-                                                        int w, u32* __restrict__ poscnt, u32* __restrict__ total) {
+                                                        int w, u32* __restrict__ poscnt) {
     const u32 seg = blockIdx.y;
     const u64 r = rs.seg_read_off[seg] + (u64)blockIdx.x * GASM_WG + threadIdx.x;
     if (r >= rs.seg_read_off[seg + 1]) return;
@@ -94,9 +94,51 @@ __global__ void __launch_bounds__(GASM_WG) k_read_match(ReadSet rs, PathSet ps, 
         }
         if (!same) continue;
         last_path = c;
-        atomicAdd(&poscnt[best], 1u);
-        atomicAdd(&total[c], 1u);
+        atomicAdd(&poscnt[best], 1u);   // kmer_breaks of the path = sum of its position counters (k_path_reduce)
     }
+}
+
+// Batch path: the paths are the contigs of the same build, so the index already exists.  A read of length >= k starts
+// with a k-mer; that k-mer is one distinct edge (2-level search in the sorted list); list ranking left (head, distance)
+// on every edge, i.e. the contig and the offset of the k-mer inside it.  Every k-mer lies on at most one contig, once,
+// so this is the only place the read can occur: compare the rest of the read there (lib/DeNovoAssembler.cpp:360).
+__global__ void __launch_bounds__(GASM_WG) k_read_match_graph(ReadSet rs, GraphView gv, const u8* __restrict__ eflag,
+                                                              const u64* __restrict__ link, const u32* __restrict__ e_cid,
+                                                              PathSet ps, u32* __restrict__ poscnt) {
+    const u32 seg = blockIdx.y;
+    const u64 r = rs.seg_read_off[seg] + (u64)blockIdx.x * GASM_WG + threadIdx.x;
+    if (r >= rs.seg_read_off[seg + 1]) return;
+    u64 p0; u32 len;
+    if (rs.fixed_len) { p0 = r * rs.fixed_len; len = rs.fixed_len; }
+    else { p0 = rs.read_off[r]; len = (u32)(rs.read_off[r + 1] - p0); }
+    if (len < (u32)gv.k) return;
+    const u64 key = kmer_at(rs.words, p0, gv.k);
+    const u32 nb = 1u << gv.bbits;
+    const u32 bkt = gv.bbits ? (u32)(key >> (2 * gv.k - gv.bbits)) : 0u;
+    const u32 lo = gv.dstart[seg * nb + bkt], hi = gv.dstart[seg * nb + bkt + 1];
+    const u32 e = lower_bound_dev<u64>(gv.dk_key, lo, hi, key);
+    if (e >= hi || gv.dk_key[e] != key) return;
+    const u64 l = link[e];
+    const u32 a = (u32)(l >> 32);
+    if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;   // on an isolated cycle: part of no contig
+    (void)eflag;
+    const u32 c = e_cid[a];
+    const u64 pb = ps.p_off[c];
+    const u64 g = pb + ((u32)l & 0x7FFFFFFFu);
+    if (g + len > ps.p_off[c + 1]) return;
+    bool same = true;
+    for (u32 o = 0; o < len && same; o += 32) {
+        const u32 nbase = len - o < 32 ? len - o : 32;
+        const u64 x = window32(rs.words, p0 + o), y = window32(ps.words, g + o);
+        same = ((x ^ y) >> (64 - 2 * nbase)) == 0;
+    }
+    if (same) atomicAdd(&poscnt[g], 1u);
+}
+
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
 }
 
 __device__ __forceinline__ double wave_sum_fixed(double v) {
@@ -105,8 +147,10 @@ __device__ __forceinline__ double wave_sum_fixed(double v) {
     return v;
 }
 
-// One wave per path.  Lane l sums positions l, l+64, ... in order; the 64 partials are combined by a fixed butterfly.
-__global__ void __launch_bounds__(GASM_WG) k_path_reduce(PathSet ps, const u32* __restrict__ poscnt, const u32* __restrict__ total,
+// One wave per path.  First the integer total of the path's position counters (= kmer_breaks; `extra` holds what
+// empty reads add to empty paths), then lane l sums positions l, l+64, ... in order and the 64 partials are combined
+// by a fixed butterfly.
+__global__ void __launch_bounds__(GASM_WG) k_path_reduce(PathSet ps, const u32* __restrict__ poscnt, const u32* __restrict__ extra,
                                                          const double* __restrict__ dprob, int kmer, double* __restrict__ bp_score,
                                                          double* __restrict__ norm_freq, double* __restrict__ norm_len,
                                                          int32_t* __restrict__ kmer_breaks, int32_t* __restrict__ seq_len, u32 n_paths) {
@@ -115,7 +159,9 @@ __global__ void __launch_bounds__(GASM_WG) k_path_reduce(PathSet ps, const u32* 
     const u32 lane = threadIdx.x & 63;
     const u64 pb = ps.p_off[p];
     const u32 len = (u32)(ps.p_off[p + 1] - pb);
-    const u32 tot = total[p];
+    u32 tsum = 0;
+    for (u32 j = lane; j < len; j += 64) tsum += poscnt[pb + j];
+    const u32 tot = wave_sum_u32(tsum) + extra[p];
     const double dtot = (double)tot;
     double s1 = 0.0, s2 = 0.0;
     for (u32 j = lane; j < len; j += 64) {

@@ -35,7 +35,11 @@ struct DevPaths {
     std::vector<u32> h_seg_path_off;        // n_segments+1
     std::vector<u64> h_seg_base_off;        // n_segments+1: first base of each segment's paths
     DBuf d_words, d_p_off, d_seg_path_off, d_seg_base_off;
-    // set when the object owns packed words built from an ASCII stream already on the device
+    // borrowed device directories (the contigs of a build): used instead of the owned buffers when set
+    const u64* b_p_off = nullptr;
+    const u32* b_seg_path_off = nullptr;
+    const u64* b_seg_base_off = nullptr;
+    const u64* seg_base_off_dev() const { return b_seg_base_off ? b_seg_base_off : d_seg_base_off.as<u64>(); }
     int pack_from_device_ascii(gasm_ctx* ctx, const u8* d_ascii);
     int upload_ascii(gasm_ctx* ctx, const char* data, const u64* off, u32 n_paths);
     int upload_dirs(gasm_ctx* ctx);
@@ -51,9 +55,9 @@ struct BuildState {
     std::vector<u32> h_dstart;              // n_segments*nb+1
     std::vector<u32> h_seg_cstart;          // n_segments+1
     std::vector<u64> h_seg_bstart;          // n_segments+1
-    DBuf d_keys, d_mult, d_hist, d_bstart, d_cursor, d_bucket_d, d_dstart, d_flags;
+    DBuf d_keys, d_mult, d_hist, d_tcnt, d_bstart, d_cursor, d_bucket_d, d_dstart, d_flags;
     DBuf d_dk_key, d_dk_cnt, d_eflag, d_nxt, d_link, d_clen, d_ecid, d_ecoff;
-    DBuf d_seg_ncontig, d_seg_cbases, d_seg_cstart, d_seg_bstart, d_c_off, d_contig_ascii;
+    DBuf d_seg_cbases, d_seg_cstart, d_seg_bstart, d_c_off, d_contig_ascii;
     // host copies filled by fetch
     std::vector<u64> h_seg_doff, h_dk_key, h_c_off, h_seg_coff;
     std::vector<u32> h_dk_cnt;
@@ -88,6 +92,7 @@ int pipeline_fetch_distinct(gasm_ctx* ctx, const DevReads& rd, BuildState& bs);
 int pipeline_fetch_contigs(gasm_ctx* ctx, const DevReads& rd, BuildState& bs);
 // paths of the build as a DevPaths (packs the contig text on the device)
 int pipeline_contig_paths(gasm_ctx* ctx, const DevReads& rd, const BuildState& bs, DevPaths& dp);
+// graph != nullptr: dp holds the contigs of that build (same order), so reads are matched through the edge list
 int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, const ScoreTable& tb, bool want_freq,
-                          bool want_pd, ScoreState& ss);
+                          bool want_pd, ScoreState& ss, const BuildState* graph);
 int pipeline_score_fetch(gasm_ctx* ctx, ScoreState& ss);

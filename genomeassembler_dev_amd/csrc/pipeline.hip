@@ -16,13 +16,28 @@ __global__ void k_add_empty_reads(PathSet ps, const u64* __restrict__ seg_empty,
     if (p >= ps.seg_path_off[seg + 1]) return;
     const u32 e = (u32)seg_empty[seg];
     if (!e) return;
-    total[p] += e;
     if (ps.p_off[p + 1] > ps.p_off[p]) poscnt[ps.p_off[p]] += e;
+    else total[p] += e;   // an empty path has no position counter: carried as an extra addend
 }
 
 static int h2d(gasm_ctx* ctx, DBuf& b, const void* src, size_t bytes) {
     GCHK(b.ensure(bytes ? bytes : 8));
     if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GASM_OK;
+}
+
+// Device -> host copy of a small array, then wait.  Goes through the ctx's pinned area (a pageable destination makes
+// hipMemcpyAsync stage through the runtime and costs tens of microseconds more per call).
+static int d2h_sync(gasm_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) { HIPCHK(hipStreamSynchronize(ctx->stream)); return GASM_OK; }
+    if (bytes <= ctx->h_pin_words * sizeof(u64)) {
+        HIPCHK(hipMemcpyAsync(ctx->h_pin, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        memcpy(dst, ctx->h_pin, bytes);
+    } else {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return GASM_OK;
 }
 
@@ -149,6 +164,7 @@ int DevPaths::pack_from_device_ascii(gasm_ctx* ctx, const u8* d_ascii) {
 
 int DevPaths::upload_ascii(gasm_ctx* ctx, const char* data, const u64* off, u32 np) {
     n_segments = 1; n_paths = np;
+    b_p_off = nullptr; b_seg_path_off = nullptr; b_seg_base_off = nullptr;
     h_p_off.resize((size_t)np + 1);
     for (u32 i = 0; i <= np; ++i) {
         if (i && off[i] < off[i - 1]) { gasm_set_error("path offsets not monotone"); return GASM_ERR_INVALID; }
@@ -168,8 +184,8 @@ int DevPaths::upload_ascii(gasm_ctx* ctx, const char* data, const u64* off, u32 
 PathSet DevPaths::view() const {
     PathSet v;
     v.words = d_words.as<u64>();
-    v.p_off = d_p_off.as<u64>();
-    v.seg_path_off = d_seg_path_off.as<u32>();
+    v.p_off = b_p_off ? b_p_off : d_p_off.as<u64>();
+    v.seg_path_off = b_seg_path_off ? b_seg_path_off : d_seg_path_off.as<u32>();
     v.n_segments = n_segments;
     return v;
 }
@@ -177,8 +193,8 @@ PathSet DevPaths::view() const {
 void DevPaths::release() { d_words.release(); d_p_off.release(); d_seg_path_off.release(); d_seg_base_off.release(); }
 
 void BuildState::release() {
-    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
-                    &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_seg_ncontig, &d_seg_cbases, &d_seg_cstart,
+    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_tcnt, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
+                    &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_seg_cbases, &d_seg_cstart,
                     &d_seg_bstart, &d_c_off, &d_contig_ascii})
         b->release();
 }
@@ -218,7 +234,11 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     u32 g = next_pow2_u32((nk_max + GASM_KT - 1) / GASM_KT);
     g = std::max(1u, std::min(64u, g));
     const u32 ipt = GASM_WG / g;
-    GCHK(rd.set_tiles(ctx, ipt));
+    // a scatter tile = tr read groups x orr offset rounds (orr > 1 only for reads longer than g*KT k-mers)
+    const u32 orr = std::max(1u, (nk_max + g * GASM_KT - 1) / (g * GASM_KT));
+    if (orr > GASM_RT_MAX) { gasm_set_error("reads longer than %u bases are not supported", 64u * GASM_KT * GASM_RT_MAX); return GASM_ERR_CAPACITY; }
+    const u32 tr = orr == 1 ? 4u : 1u;
+    GCHK(rd.set_tiles(ctx, ipt * tr));
     // bucket bits: aim at ~1400 distinct k-mers per bucket (the LDS table takes 2816)
     const int bb_cap = std::min(10, 2 * (k - 1));
     int bbits = 0;
@@ -228,6 +248,18 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     }
     GCHK(bs.d_flags.ensure(64));
     bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
+    // small (2048-slot) LDS tables when the expected number of distinct k-mers per bucket is small: more workgroups per CU
+    bool small_tbl;
+    {
+        const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
+        small_tbl = (dest >> bbits) <= 800;
+    }
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_attr_set = true;
+    }
     if (N == 0) {
         bs.bbits = 0;
         bs.h_dstart.assign((size_t)S + 1, 0);
@@ -246,28 +278,45 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         const u32 nb = 1u << bbits;
         nbt = S * nb;
         GCHK(bs.d_hist.ensure((size_t)nbt * 4));
+        GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 4));
         GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
-        GCHK(bs.d_dstart.ensure(((size_t)nbt + 1) * 4));
-        HIPCHK(hipMemsetAsync(bs.d_hist.p, 0, (size_t)nbt * 4, ctx->stream));
+        GCHK(bs.d_dstart.ensure(((size_t)nbt + 2) * 4));
         HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 64, ctx->stream));
-        GLAUNCH(ctx, "k_bucket_hist", k_bucket_hist, dim3(grid_tiles), dim3(GASM_WG), nb * 4, rs, k, bbits, g, rd.n_tiles,
+        GLAUNCH(ctx, "k_tile_hist", k_tile_hist, dim3(grid_tiles), dim3(GASM_WG), nb * 4, rs, k, bbits, g, tr, rd.n_tiles,
+                bs.d_tcnt.as<u32>());
+        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(std::min(1024u, std::max(64u, nb))), 0, rs, bbits, bs.d_tcnt.as<u32>(),
                 bs.d_hist.as<u32>());
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
-        HIPCHK(hipMemcpyAsync(bs.d_cursor.p, bs.d_bstart.p, (size_t)nbt * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        const size_t lds = (size_t)GASM_KT * GASM_WG * 8 + (size_t)nb * 16 + 32 + (size_t)GASM_KT * GASM_WG * 2;
-        GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter, dim3(grid_tiles), dim3(GASM_WG), lds, rs, k, bbits, g, rd.n_tiles,
-                bs.d_cursor.as<u64>(), bs.d_keys.as<u64>());
-        GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>());
+        const u32 rt = tr * orr;
+        const size_t lds = (size_t)GASM_KT * GASM_WG * 10 + (size_t)nb * (16 + 32 * rt + 64);
+        if (lds > 160 * 1024) { gasm_set_error("scatter tile does not fit LDS (%zu bytes)", lds); return GASM_ERR_CAPACITY; }
+        if (rt == 4) {
+            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<4>, dim3(grid_tiles), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_keys.as<u64>());
+        } else {
+            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<0>, dim3(grid_tiles), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_keys.as<u64>());
+        }
+        if (small_tbl) {
+            GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup<2048>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), 2 * k - bbits);
+        } else {
+            GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup<4096>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), 2 * k - bbits);
+        }
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt);
         bs.h_dstart.resize((size_t)nbt + 1);
         u32 hflags[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(bs.h_dstart.data(), bs.d_dstart.p, ((size_t)nbt + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(hflags, bs.d_flags.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        // the overflow flag rides behind the directory so one copy + one wait fetches both
+        HIPCHK(hipMemcpyAsync(bs.d_dstart.as<u32>() + nbt + 1, bs.d_flags.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        bs.h_dstart.resize((size_t)nbt + 2);
+        GCHK(d2h_sync(ctx, bs.h_dstart.data(), bs.d_dstart.p, ((size_t)nbt + 2) * 4));
+        hflags[0] = bs.h_dstart[(size_t)nbt + 1];
+        bs.h_dstart.resize((size_t)nbt + 1);
         if (!hflags[0]) break;
+        if (small_tbl) { small_tbl = false; continue; }   // same partition, larger tables
         if (bbits >= bb_cap) {
             gasm_set_error("a k-mer bucket holds more than %d distinct k-mers even with %d bucket bits", GASM_TBL_LIMIT, bbits);
             return GASM_ERR_CAPACITY;
@@ -294,8 +343,8 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     GCHK(bs.d_clen.ensure((size_t)D * 4));
     GCHK(bs.d_ecid.ensure((size_t)D * 4));
     GCHK(bs.d_ecoff.ensure((size_t)D * 8));
-    GCHK(bs.d_seg_ncontig.ensure((size_t)S * 4));
-    GCHK(bs.d_seg_cbases.ensure((size_t)S * 8));
+    GCHK(bs.d_seg_cbases.ensure((size_t)S * 8 + (size_t)S * 4));   // u64 bases[S] then u32 counts[S]: one read-back
+    u32* d_seg_ncontig = reinterpret_cast<u32*>(bs.d_seg_cbases.as<u64>() + S);
     HIPCHK(hipMemsetAsync(bs.d_link.p, 0xFF, (size_t)D * 8, ctx->stream));
     HIPCHK(hipMemsetAsync(bs.d_clen.p, 0, (size_t)D * 4, ctx->stream));
     GraphView gv;
@@ -310,20 +359,22 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     int rounds = 1;
     while ((1ull << rounds) < (u64)maxD) ++rounds;
     rounds += 1;
-    for (int r = 0; r < rounds; ++r)
-        GLAUNCH(ctx, "k_link_jump", k_link_jump, grid_all, dim3(GASM_WG), 0, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), D);
+    if (maxD <= (1u << 18)) {
+        // one workgroup per segment runs every round (early exit); enough for segments up to 256k distinct k-mers
+        GLAUNCH(ctx, "k_link_rank_seg", k_link_rank_seg, dim3(S), dim3(1024), 0, gv, bs.d_link.as<u64>(), rounds + 1);
+    } else {
+        for (int r = 0; r < rounds; ++r) GLAUNCH(ctx, "k_link_jump", k_link_jump, grid_all, dim3(GASM_WG), 0, bs.d_link.as<u64>(), D);
+    }
     GLAUNCH(ctx, "k_chain_len", k_chain_len, grid_all, dim3(GASM_WG), 0, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>(),
             bs.d_clen.as<u32>(), D);
     GLAUNCH(ctx, "k_contig_scan", k_contig_scan, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
-            bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_seg_ncontig.as<u32>(), bs.d_seg_cbases.as<u64>());
-    std::vector<u32> h_nc(S);
-    std::vector<u64> h_cb(S);
-    HIPCHK(hipMemcpyAsync(h_nc.data(), bs.d_seg_ncontig.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(h_cb.data(), bs.d_seg_cbases.p, (size_t)S * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+            bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), d_seg_ncontig, bs.d_seg_cbases.as<u64>());
+    std::vector<u64> h_cbnc((size_t)S + (S + 1) / 2);
+    GCHK(d2h_sync(ctx, h_cbnc.data(), bs.d_seg_cbases.p, (size_t)S * 12));
+    const u32* h_nc = reinterpret_cast<const u32*>(h_cbnc.data() + S);
     for (u32 s = 0; s < S; ++s) {
         bs.h_seg_cstart[s + 1] = bs.h_seg_cstart[s] + h_nc[s];
-        bs.h_seg_bstart[s + 1] = bs.h_seg_bstart[s] + h_cb[s];
+        bs.h_seg_bstart[s + 1] = bs.h_seg_bstart[s] + h_cbnc[s];
     }
     bs.n_contigs = bs.h_seg_cstart[S];
     bs.contig_bases = bs.h_seg_bstart[S];
@@ -377,19 +428,28 @@ int pipeline_fetch_contigs(gasm_ctx* ctx, const DevReads& rd, BuildState& bs) {
 }
 
 int pipeline_contig_paths(gasm_ctx* ctx, const DevReads& rd, const BuildState& bs, DevPaths& dp) {
+    // the contigs of a build as paths: offsets and directories are the build's own device arrays (borrowed, no copy,
+    // no host round trip); only the 2-bit packing of the contig text is new
     const u32 S = rd.n_segments;
     dp.n_segments = S;
     dp.n_paths = bs.n_contigs;
     dp.total_bases = bs.contig_bases;
     dp.h_seg_path_off.assign(bs.h_seg_cstart.begin(), bs.h_seg_cstart.end());
-    if (dp.h_seg_path_off.size() != (size_t)S + 1) dp.h_seg_path_off.assign((size_t)S + 1, 0);
-    dp.h_p_off.assign((size_t)bs.n_contigs + 1, 0);
-    if (bs.n_contigs) {
-        HIPCHK(hipMemcpyAsync(dp.h_p_off.data(), bs.d_c_off.p, ((size_t)bs.n_contigs + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+    dp.h_seg_base_off.assign(bs.h_seg_bstart.begin(), bs.h_seg_bstart.end());
+    if (dp.h_seg_path_off.size() != (size_t)S + 1) { dp.h_seg_path_off.assign((size_t)S + 1, 0); dp.h_seg_base_off.assign((size_t)S + 1, 0); }
+    dp.h_p_off.clear();
+    dp.b_p_off = bs.n_contigs ? bs.d_c_off.as<u64>() : nullptr;
+    dp.b_seg_path_off = bs.d_seg_cstart.as<u32>();
+    dp.b_seg_base_off = bs.d_seg_bstart.as<u64>();
+    if (!bs.n_contigs) {
+        // nothing to borrow: empty directories of our own
+        dp.h_p_off.assign(1, 0);
+        dp.b_p_off = nullptr; dp.b_seg_path_off = nullptr; dp.b_seg_base_off = nullptr;
+        GCHK(dp.d_words.ensure(32));
+        HIPCHK(hipMemsetAsync(dp.d_words.p, 0, 32, ctx->stream));
+        return dp.upload_dirs(ctx);
     }
-    GCHK(dp.pack_from_device_ascii(ctx, bs.d_contig_ascii.as<u8>()));
-    return dp.upload_dirs(ctx);
+    return pack_ascii(ctx, bs.d_contig_ascii.as<u8>(), bs.contig_bases, dp.d_words, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -446,7 +506,7 @@ void ScoreTable::release() { d_prob.release(); d_row.release(); }
 // score: pipeline_score_launch queues everything on the stream; pipeline_score_fetch copies the results back.
 // ---------------------------------------------------------------------------------------------------------------
 int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, const ScoreTable& tb, bool want_freq, bool want_pd,
-                          ScoreState& ss) {
+                          ScoreState& ss, const BuildState* graph) {
     if (kmer < 0) { gasm_set_error("kmer must be >= 0"); return GASM_ERR_INVALID; }
     if (rd.n_segments != dp.n_segments) { gasm_set_error("reads and paths disagree on the number of segments"); return GASM_ERR_INVALID; }
     HIPCHK(hipSetDevice(ctx->device));
@@ -465,7 +525,18 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
     HIPCHK(hipMemsetAsync(ss.d_total.p, 0, ((size_t)P + 1) * 4, ctx->stream));
     const PathSet ps = dp.view();
     const int w = (int)std::min<u32>(32, rd.min_len);
-    if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
+    if (graph && P && TB && rd.n_reads > rd.n_empty && rd.min_len >= (u32)graph->k && graph->d_total) {
+        // the paths are this build's contigs and every read holds a k-mer: the sorted edge list is the index
+        GraphView gv;
+        gv.dk_key = graph->d_dk_key.as<u64>();
+        gv.dstart = graph->d_dstart.as<u32>();
+        gv.k = graph->k;
+        gv.bbits = graph->bbits;
+        u64 max_reads = 0;
+        for (u32 s = 0; s < S; ++s) max_reads = std::max(max_reads, rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]);
+        GLAUNCH(ctx, "k_read_match_graph", k_read_match_graph, dim3(ceil_div_u64(max_reads, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), gv,
+                graph->d_eflag.as<u8>(), graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, ss.d_poscnt.as<u32>());
+    } else if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
         // per-segment seed tables: power-of-two, at least twice the number of path positions
         std::vector<u64>& toff = ss.h_toff;
         toff.assign((size_t)S + 1, 0);
@@ -488,9 +559,9 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
         st.tbl_off = ss.d_tbl_off.as<u64>();
         if (max_bases) {
             GLAUNCH(ctx, "k_seed_insert", k_seed_insert, dim3(ceil_div_u64(max_bases, GASM_WG), S), dim3(GASM_WG), 0, ps, st,
-                    dp.d_seg_base_off.as<u64>(), w);
+                    dp.seg_base_off_dev(), w);
             GLAUNCH(ctx, "k_read_match", k_read_match, dim3(ceil_div_u64(max_reads, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), ps, st,
-                    dp.d_seg_base_off.as<u64>(), w, ss.d_poscnt.as<u32>(), ss.d_total.as<u32>());
+                    dp.seg_base_off_dev(), w, ss.d_poscnt.as<u32>());
         }
     }
     if (P && rd.n_empty) {
