@@ -37,16 +37,15 @@ struct PathSet {
 
 // ---- kernels_build.hip
 __global__ void k_pack_ascii(const u8* ascii, u64 nbases, u64* words, u64 nwords, u32* err);
-__global__ void k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 n_tiles, u32* tcnt);
-__global__ void k_tile_scan(ReadSet rs, int bbits, u32* tcnt, u32* hist);
+__global__ void k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles, u16* cube);
+__global__ void k_tile_scan(ReadSet rs, int bbits, u32 rt4, const u16* cube, u32* toff, u32* hist);
 template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
 __global__ void k_copy_u64(const u64* a, u64* b, u32 n);
-template <int RT_T>
 __global__ void k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles, const u64* bstart,
-                                 const u32* toff, u64* keys);
+                                 const u32* toff, const u16* cube, u64* keys, int dbg);
 #define GASM_RT_MAX 16      // rounds (read groups x offset rounds) one scatter tile may hold
 template <int TBL>
-__global__ void k_bucket_dedup(u64* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, int low_bits);
+__global__ void k_bucket_dedup(u64* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, int low_bits, int dbg);
 __global__ void k_bucket_gather(const u64* keys, const u32* mult, const u64* bstart, const u32* dstart, u64* dk_key,
                                 u32* dk_cnt);
 __global__ void k_node_flags(GraphView gv, u8* eflag);

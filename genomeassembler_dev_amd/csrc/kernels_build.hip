@@ -17,6 +17,8 @@
 #include "device_utils.h"
 #include "kernels.h"
 
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
 // ================================================================================================================
 // ASCII -> 2-bit.  One thread per output word (32 bases); 2 x 16-byte loads where the word is fully inside.
 // ================================================================================================================
@@ -93,16 +95,19 @@ __device__ __forceinline__ u64 roll_window(const Roll3& r, u32 j) {
     return (x << o) | ((y >> 1) >> (63 - o));
 }
 
-// Per-tile k-mer histogram over buckets: tcnt[tile * nb + b].  The bucket of a k-mer is its first `bbits` bits
-// (bbits <= 2(k-1), bbits <= 10), i.e. buckets are key ranges: concatenating sorted buckets gives a sorted segment.
-// A tile is `tr` groups of GASM_WG/g reads (tile_decode is given ipt*tr).
-__global__ void __launch_bounds__(GASM_WG) k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 n_tiles,
-                                                       u32* __restrict__ tcnt) {
-    extern __shared__ u32 s_h[];
-    const u32 nb = 1u << bbits, ipt = GASM_WG / g;
-    const u32 item = threadIdx.x / g, lane = threadIdx.x % g;
+// Count cube: for every tile, bucket, round q and wave w the number of k-mers wave w meets in round q of the tile
+// that fall into the bucket — cube[(tile * nb + b) * rt4 + q * 4 + w], 16-bit (a wave-round holds at most 1024).
+// The bucket of a k-mer is its first `bbits` bits (bbits <= 2(k-1), bbits <= 10), i.e. buckets are key ranges:
+// concatenating sorted buckets gives a sorted segment.  A tile is `tr` groups of GASM_WG/g reads x `orr` offset rounds;
+// round q = t * orr + o handles read group t, k-mer starts o*g*KT + lane*KT + [0, KT).  k_bucket_scatter walks the tile
+// in exactly the same order, so it needs no counting of its own.
+__global__ void __launch_bounds__(GASM_WG) k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles,
+                                                       u16* __restrict__ cube) {
+    extern __shared__ u32 s_h[];   // [rt][4][nb]
+    const u32 nb = 1u << bbits, ipt = GASM_WG / g, rt = tr * orr, rt4 = rt * 4;
+    const u32 item = threadIdx.x / g, lane = threadIdx.x % g, wv = threadIdx.x >> 6;
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        for (u32 b = threadIdx.x; b < nb; b += GASM_WG) s_h[b] = 0;
+        for (u32 e = threadIdx.x; e < rt4 * nb; e += GASM_WG) s_h[e] = 0;
         __syncthreads();
         const TileInfo ti = tile_decode(rs, tile, ipt * tr);
         for (u32 t = 0; t < tr; ++t) {
@@ -111,44 +116,51 @@ __global__ void __launch_bounds__(GASM_WG) k_tile_hist(ReadSet rs, int k, int bb
             u64 p0; u32 len;
             read_span(rs, ti.r0 + it, &p0, &len);
             const u32 nk = len >= (u32)k ? len - k + 1 : 0;
-            for (u32 off0 = lane * GASM_KT; off0 < nk; off0 += g * GASM_KT) {
+            for (u32 o = 0; o < orr; ++o) {
+                const u32 off0 = o * g * GASM_KT + lane * GASM_KT;
+                if (off0 >= nk) break;
                 const Roll3 r = roll_load(rs.words, p0 + off0);
+                u32* row = s_h + ((t * orr + o) * 4 + wv) * nb;
 #pragma unroll
                 for (u32 j = 0; j < GASM_KT; ++j) {
                     if (off0 + j < nk) {
                         const u32 bkt = bbits ? (u32)(roll_window(r, j) >> (64 - bbits)) : 0u;
-                        atomicAdd(&s_h[bkt], 1u);
+                        atomicAdd(&row[bkt], 1u);
                     }
                 }
             }
         }
         __syncthreads();
-        for (u32 b = threadIdx.x; b < nb; b += GASM_WG) tcnt[(u64)tile * nb + b] = s_h[b];
+        u16* dst = cube + (u64)tile * nb * rt4;
+        for (u32 e = threadIdx.x; e < rt4 * nb; e += GASM_WG) {
+            const u32 b = e / rt4, qw = e - b * rt4;
+            dst[e] = (u16)s_h[qw * nb + b];
+        }
         __syncthreads();
     }
 }
 
-// Per segment and bucket: running sum of the tile counts (in place: tcnt becomes each tile's offset inside its
-// (segment,bucket) range) and the bucket total hist[seg * nb + b].  One workgroup per segment, thread = bucket.
-__global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32* __restrict__ tcnt, u32* __restrict__ hist) {
+// Per segment and bucket: tile totals from the cube, their running sum toff[tile * nb + b] (offset of the tile inside
+// its (segment,bucket) range) and the bucket total hist[seg * nb + b].  One workgroup per segment, thread = bucket.
+__global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 rt4, const u16* __restrict__ cube,
+                                                    u32* __restrict__ toff, u32* __restrict__ hist) {
     const u32 nb = 1u << bbits, seg = blockIdx.x;
     const u32 t0 = rs.seg_tile_start[seg], t1 = rs.seg_tile_start[seg + 1];
     for (u32 b = threadIdx.x; b < nb; b += blockDim.x) {
         u32 run = 0;
-        u32 t = t0;
-        for (; t + 4 <= t1; t += 4) {
-            const u32 c0 = tcnt[(u64)t * nb + b], c1 = tcnt[(u64)(t + 1) * nb + b], c2 = tcnt[(u64)(t + 2) * nb + b],
-                      c3 = tcnt[(u64)(t + 3) * nb + b];
-            tcnt[(u64)t * nb + b] = run;
-            tcnt[(u64)(t + 1) * nb + b] = run + c0;
-            tcnt[(u64)(t + 2) * nb + b] = run + c0 + c1;
-            tcnt[(u64)(t + 3) * nb + b] = run + c0 + c1 + c2;
-            run += c0 + c1 + c2 + c3;
-        }
-        for (; t < t1; ++t) {
-            const u32 c = tcnt[(u64)t * nb + b];
-            tcnt[(u64)t * nb + b] = run;
-            run += c;
+        for (u32 t = t0; t < t1; ++t) {
+            const u16* c = cube + ((u64)t * nb + b) * rt4;
+            u32 tot = 0;
+            if ((rt4 & 7) == 0) {
+                for (u32 e = 0; e < rt4; e += 8) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(c + e);
+                    tot += (v.x & 0xFFFF) + (v.x >> 16) + (v.y & 0xFFFF) + (v.y >> 16) + (v.z & 0xFFFF) + (v.z >> 16) + (v.w & 0xFFFF) + (v.w >> 16);
+                }
+            } else {
+                for (u32 e = 0; e < rt4; ++e) tot += c[e];
+            }
+            toff[(u64)t * nb + b] = run;
+            run += tot;
         }
         hist[(u64)seg * nb + b] = run;
     }
@@ -179,138 +191,120 @@ __global__ void k_copy_u64(const u64* __restrict__ a, u64* __restrict__ b, u32 n
 
 // ================================================================================================================
 // Scatter: every k-mer of every read is written once, 8 bytes, into its (segment,bucket) range of `keys`.
-// The output range of a (tile,bucket) is known beforehand: bstart[seg,bucket] + toff[tile,bucket]
-// (k_tile_hist/k_tile_scan), so there is no global atomic and the layout is deterministic.
-//
-// A tile is RT rounds (tr read groups x `orr` offset rounds) of up to 4096 k-mers.  Pass 1 counts every round's
-// k-mers per (round, wave, bucket) in LDS; ONE workgroup barrier; after it the four waves never meet again in this
-// tile: for each round a wave derives its slice of every bucket's range from the count cube, ranks its k-mers into
-// wave-private bins (ds_add_rtn), stages them bucket by bucket in its private LDS area and streams them out, so the
-// global stores of one bucket are consecutive.  The count cube and the tile bases are double buffered by tile parity so
-// a fast wave can start the next tile while a slow one finishes this one.
-// LDS: per wave KT*64 keys (8 B) + bucket ids (2 B) + nb*16; shared 2*RT*4*nb*4 + 2*nb*8  (54 272 B at nb = 64, RT = 4:
-// three workgroups per CU).
+// Where a wave's k-mers of one round go is fully determined beforehand: bstart[seg,bucket] + toff[tile,bucket]
+// (k_tile_scan) + the cube counts of the earlier rounds and the lower waves (k_tile_hist).  So there is no global
+// atomic, no counting pass and no workgroup barrier: each wave ranks its 1024 k-mers of a round into wave-private LDS
+// bins (one ds_add_rtn per k-mer on a cursor that starts at the bin's staging offset), then streams the staged keys
+// out bucket by bucket — the global stores of one bucket are consecutive — looking up one combined 64-bit base per key.
+// The output layout is deterministic.  LDS per wave: 1024 keys (8 KB) + nb * 12 + 8.
 // ================================================================================================================
 __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int RT_T>   // rounds per tile known at compile time (4), or 0 = run-time value
 __global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles,
                                                             const u64* __restrict__ bstart, const u32* __restrict__ toff,
-                                                            u64* __restrict__ keys) {
+                                                            const u16* __restrict__ cube, u64* __restrict__ keys, int dbg) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     constexpr u32 WSTAGE = GASM_KT * 64;
-    const u32 RT = RT_T ? (u32)RT_T : tr * orr;
+    const u32 rt = tr * orr, rt4 = rt * 4;
     const u32 nb = 1u << bbits, ipt = GASM_WG / g;
     const u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    // carve LDS
-    u64* s_key_all = reinterpret_cast<u64*>(s_raw);                       // 4 * WSTAGE
-    u64* s_gbase_all = s_key_all + 4 * WSTAGE;                            // 2 * nb
-    u32* s_cube_all = reinterpret_cast<u32*>(s_gbase_all + 2 * nb);       // 2 * RT * 4 * nb
-    u32* s_off_all = s_cube_all + 2 * RT * 4 * nb;                        // 4 * nb
-    u32* s_cur_all = s_off_all + 4 * nb;                                  // 4 * nb
-    u32* s_adv_all = s_cur_all + 4 * nb;                                  // 4 * nb
-    u32* s_wbase_all = s_adv_all + 4 * nb;                                // 4 * nb   (relative to the tile base)
-    u16* s_bkt_all = reinterpret_cast<u16*>(s_wbase_all + 4 * nb);        // 4 * WSTAGE
-    u64* s_key = s_key_all + wv * WSTAGE;
-    u32* s_wbase = s_wbase_all + wv * nb;
-    u32* s_off = s_off_all + wv * nb;
-    u32* s_cur = s_cur_all + wv * nb;
-    u32* s_adv = s_adv_all + wv * nb;
-    u16* s_bkt = s_bkt_all + wv * WSTAGE;
+    u64* s_key = reinterpret_cast<u64*>(s_raw) + wv * WSTAGE;                          // 4 * WSTAGE
+    u64* s_comb = reinterpret_cast<u64*>(s_raw) + 4 * WSTAGE + wv * nb;                // 4 * nb
+    u32* s_cur = reinterpret_cast<u32*>(reinterpret_cast<u64*>(s_raw) + 4 * WSTAGE + 4 * nb) + wv * (nb + 2);   // 4 * (nb + 2): + dummy bin
     const u32 item = threadIdx.x / g, lane = threadIdx.x % g;
     const int kshift = 64 - 2 * k;
-    u32 par = 0;
+    const int bshift = 2 * k - bbits;
+    const bool fast = rt4 == 16 && nb <= 64;     // one bucket per lane, the bucket's 16 counts live in registers
 
-    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
+    // a workgroup takes a contiguous range of tiles: the last cache line of one tile's run in a bucket and the first of
+    // the next tile's are the same line, and only the same L2 can merge the two partial writes into one full line
+    const u32 per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const u32 tile_end = min(n_tiles, (blockIdx.x + 1) * per_wg);
+    for (u32 tile = blockIdx.x * per_wg; tile < tile_end; ++tile) {
         const TileInfo ti = tile_decode(rs, tile, ipt * tr);
-        u64* s_gbase = s_gbase_all + par * nb;
-        u32* s_cube = s_cube_all + par * RT * 4 * nb;      // [RT][4][nb]
-        for (u32 b = threadIdx.x; b < nb; b += GASM_WG) s_gbase[b] = bstart[(u64)ti.seg * nb + b] + toff[(u64)tile * nb + b];
-        for (u32 q = 0; q < RT; ++q)
-            for (u32 b = ln; b < nb; b += 64) s_cube[(q * 4 + wv) * nb + b] = 0;
-        wave_sync_lds();
-        // ---- pass 1: count every round (this wave's rows of the cube)
-        auto round_span = [&](u32 q, u64* p0, u32* nk, u32* off0) {
-            const u32 t = q / orr, o = q - t * orr;
-            const u32 it = t * ipt + item;
-            *nk = 0; *p0 = 0;
-            if (it < ti.nitems) {
-                u32 len;
-                read_span(rs, ti.r0 + it, p0, &len);
-                *nk = len >= (u32)k ? len - k + 1 : 0;
-            }
-            *off0 = o * g * GASM_KT + lane * GASM_KT;
-        };
-#pragma unroll
-        for (u32 q = 0; q < (RT_T ? (u32)RT_T : RT); ++q) {
-            u64 p0; u32 nk, off0;
-            round_span(q, &p0, &nk, &off0);
-            if (off0 < nk) {
-                const Roll3 rl = roll_load(rs.words, p0 + off0);
-                u32* row = s_cube + (q * 4 + wv) * nb;
-#pragma unroll
-                for (u32 j = 0; j < GASM_KT; ++j) {
-                    if (off0 + j < nk) {
-                        const u32 bkt = bbits ? (u32)(roll_window(rl, j) >> (64 - bbits)) : 0u;
-                        atomicAdd(&row[bkt], 1u);
-                    }
-                }
-            }
+        u32 cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        u64 tbase = 0;
+        if (fast && ln < nb) {
+            const uint4* c4 = reinterpret_cast<const uint4*>(cube + ((u64)tile * nb + ln) * 16);
+            const uint4 v0 = c4[0], v1 = c4[1];
+            cw[0] = v0.x; cw[1] = v0.y; cw[2] = v0.z; cw[3] = v0.w; cw[4] = v1.x; cw[5] = v1.y; cw[6] = v1.z; cw[7] = v1.w;
+            tbase = bstart[(u64)ti.seg * nb + ln] + toff[(u64)tile * nb + ln];
         }
-        __syncthreads();   // the count cube and the tile bases are complete
-        // ---- pass 2: place, round by round, every wave on its own
-        for (u32 b = ln; b < nb; b += 64) s_wbase[b] = 0;   // running offset behind the tile base: all earlier rounds
-        for (u32 q = 0; q < RT; ++q) {
-            u64 p0; u32 nk, off0;
-            round_span(q, &p0, &nk, &off0);
-            // this wave's slice of every bucket in this round + staging offsets
-            u32 carry = 0;
+        u32 run_before = 0;   // fast path: k-mers of this lane's bucket in earlier rounds (all waves)
+        for (u32 q = 0; q < rt; ++q) {
+            // ---- where this wave's k-mers of round q go, bucket by bucket
+            u32 kcar = 0;
             for (u32 b0 = 0; b0 < nb; b0 += 64) {
                 const u32 b = b0 + ln;
-                u32 c = 0, lower = 0, upper = 0;
-                if (b < nb) {
-                    const u32* rows = s_cube + q * 4 * nb + b;
-                    c = rows[wv * nb];
-                    for (u32 w2 = 0; w2 < 4; ++w2) { const u32 v = rows[w2 * nb]; if (w2 < wv) lower += v; else if (w2 > wv) upper += v; }
-                }
-                const u32 inc = wave_incl_scan(c);
-                if (b < nb) {
-                    s_off[b] = carry + inc - c;
-                    s_cur[b] = 0;
-                    s_wbase[b] += lower;                     // start of this wave's slice in this round
-                    s_adv[b] = c + upper;                    // to the next round: own count + the waves above
-                }
-                carry += __shfl(inc, 63, 64);
-            }
-            wave_sync_lds();
-            if (off0 < nk) {
-                const Roll3 rl = roll_load(rs.words, p0 + off0);
+                u32 own = 0;
+                u64 base = 0;
+                if (fast) {
+                    // counts of round q: words 2q, 2q+1 = waves (0,1), (2,3)
+                    u32 w01 = 0, w23 = 0;
 #pragma unroll
-                for (u32 j = 0; j < GASM_KT; ++j) {
-                    if (off0 + j < nk) {
-                        const u64 wdw = roll_window(rl, j);
-                        const u32 bkt = bbits ? (u32)(wdw >> (64 - bbits)) : 0u;
-                        const u32 idx = s_off[bkt] + atomicAdd(&s_cur[bkt], 1u);
-                        s_key[idx] = wdw >> kshift;
-                        s_bkt[idx] = (u16)bkt;
-                    }
+                    for (u32 e = 0; e < 4; ++e) if (e == q) { w01 = cw[2 * e]; w23 = cw[2 * e + 1]; }
+                    const u32 c0 = w01 & 0xFFFF, c1 = w01 >> 16, c2 = w23 & 0xFFFF, c3 = w23 >> 16;
+                    own = wv == 0 ? c0 : wv == 1 ? c1 : wv == 2 ? c2 : c3;
+                    const u32 lower = (wv > 0 ? c0 : 0) + (wv > 1 ? c1 : 0) + (wv > 2 ? c2 : 0);
+                    base = tbase + run_before + lower;
+                    run_before += c0 + c1 + c2 + c3;
+                } else if (b < nb) {
+                    const u16* c = cube + ((u64)tile * nb + b) * rt4;
+                    u32 before = 0;
+                    for (u32 e = 0; e < q * 4 + wv; ++e) before += c[e];    // earlier rounds, and lower waves of this one
+                    own = c[q * 4 + wv];
+                    base = bstart[(u64)ti.seg * nb + b] + toff[(u64)tile * nb + b] + before;
                 }
+                const u32 inc = wave_incl_scan(own);
+                const u32 off = kcar + inc - own;                    // staging offset of the bin
+                if (b < nb) {
+                    s_cur[b] = off;
+                    s_comb[b] = base - off;                          // global index = s_comb[bucket] + staging index
+                }
+                kcar += __shfl(inc, 63, 64);
+            }
+            const u32 staged = kcar;
+            wave_sync_lds();
+            // ---- rank and stage.  The sixteen ds_add_rtn of a thread are issued back to back (a position past the end of
+            // the read ranks into a dummy bin) and waited for once; a branch per k-mer would make them sixteen dependent
+            // LDS round trips.
+            const u32 t = q / orr, o = q - t * orr;
+            const u32 it = t * ipt + item;
+            u64 p0 = 0; u32 nk = 0;
+            if (it < ti.nitems) {
+                u32 len;
+                read_span(rs, ti.r0 + it, &p0, &len);
+                nk = len >= (u32)k ? len - k + 1 : 0;
+            }
+            const u32 off0 = o * g * GASM_KT + lane * GASM_KT;
+            const bool any = off0 < nk;
+            const Roll3 rl = roll_load(rs.words, any ? p0 + off0 : 0);
+            u64 key[GASM_KT];
+            u32 idx[GASM_KT];
+#pragma unroll
+            for (u32 j = 0; j < GASM_KT; ++j) {
+                const u64 wdw = roll_window(rl, j);
+                key[j] = wdw >> kshift;
+                const u32 bkt = bbits ? (u32)(wdw >> (64 - bbits)) : 0u;
+                idx[j] = atomicAdd(&s_cur[(any && off0 + j < nk) ? bkt : nb], 1u);
+            }
+#pragma unroll
+            for (u32 j = 0; j < GASM_KT; ++j)
+                if (any && off0 + j < nk) s_key[idx[j]] = key[j];
+            wave_sync_lds();
+            // ---- stream out
+            if (dbg != 2) for (u32 i = ln; i < staged; i += 64) {
+                const u64 key = s_key[i];
+                const u32 bkt = bbits ? (u32)(key >> bshift) : 0u;
+                keys[s_comb[bkt] + i] = key;
             }
             wave_sync_lds();
-            for (u32 i = ln; i < carry; i += 64) {
-                const u32 bkt = s_bkt[i];
-                keys[s_gbase[bkt] + s_wbase[bkt] + (i - s_off[bkt])] = s_key[i];
-            }
-            wave_sync_lds();
-            for (u32 b = ln; b < nb; b += 64) s_wbase[b] += s_adv[b];
         }
     }
 }
-template __global__ void k_bucket_scatter<4>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, u64*);
-template __global__ void k_bucket_scatter<0>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, u64*);
 
 // ================================================================================================================
 // De-duplicate one bucket: stream its keys through an LDS open-addressing table (64-bit CAS on the key, 32-bit add on
@@ -320,16 +314,22 @@ template __global__ void k_bucket_scatter<0>(ReadSet, int, int, u32, u32, u32, u
 // key are finished by a per-bin insertion sort; if any bin is long (skewed keys) the workgroup falls back to a
 // bitonic sort.  A bucket with more than 11/16*TBL distinct keys raises *overflow (the host re-partitions).
 // ================================================================================================================
+// 16-byte LDS read that the compiler may not reuse from an earlier read (other lanes change the table meanwhile)
+__device__ __forceinline__ u64x2 lds_load128(const u64* p) {
+    __asm__ volatile("" ::: "memory");
+    return *reinterpret_cast<const u64x2*>(p);
+}
+
 template <int TBL>
 __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys, u32* __restrict__ mult,
                                                           const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
-                                                          u32* __restrict__ overflow, int low_bits) {
+                                                          u32* __restrict__ overflow, int low_bits, int dbg) {
     constexpr int LIMIT = TBL / 16 * 11;
     constexpr int BINS = TBL / 4;
     constexpr int SL = TBL / GASM_WG;
     constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
     static_assert(TBL == 4096 || TBL == 2048, "table size");
-    __shared__ u64 t_key[TBL];
+    __shared__ __align__(32) u64 t_key[TBL];
     __shared__ u32 t_cnt[TBL];
     __shared__ u32 s_start[BINS];
     __shared__ u32 s_cur[BINS];
@@ -341,20 +341,33 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys
     for (u32 i = threadIdx.x; i < BINS; i += GASM_WG) s_start[i] = 0;
     if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }  // [4] distinct so far, [5] overflow, [6] longest bin
     __syncthreads();
-    // insert with a bounded probe sequence (a full table raises the overflow flag instead of spinning)
-    auto insert = [&](u64 key) {
-        u32 h = hash64(key) >> (32 - LOG_TBL);
-        for (u32 probe = 0; probe < TBL; ++probe) {
-            const u64 cur = __hip_atomic_load(&t_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (cur == key) { atomicAdd(&t_cnt[h], 1u); return; }
-            if (cur == GASM_EMPTY64) {
-                const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&t_key[h]), (unsigned long long)GASM_EMPTY64,
-                                          (unsigned long long)key);
-                if (old == GASM_EMPTY64) { atomicAdd(&s_tmp[4], 1u); atomicAdd(&t_cnt[h], 1u); return; }
-                if (old == key) { atomicAdd(&t_cnt[h], 1u); return; }
-            }
-            h = (h + 1) & (TBL - 1);
+    // The table is TBL/4 sets of four slots (32 bytes).  A key lives in the first set with room, counted from its
+    // home set; sets fill left to right.  One probe = the whole set (2 x ds_read_b128), so unless a home set has
+    // overflowed (rare at <= 30 % load) a key is found in the first probe — which matters because a wave moves at the
+    // pace of its slowest lane: with one-slot probing some lane of 64 always needs a second and third round.
+    constexpr u32 NSETS = TBL / 4;
+    constexpr int LOG_SETS = LOG_TBL - 2;
+    // one step for one key on set `set`: returns true when the key is counted, false to probe again (same set after a
+    // lost race, next set when this one is full of other keys)
+    auto step = [&](u64 key, u32& set) -> bool {
+        const u64x2 c01 = lds_load128(&t_key[4 * set]);
+        const u64x2 c23 = lds_load128(&t_key[4 * set + 2]);
+        int slot = c01.x == key ? 0 : c01.y == key ? 1 : c23.x == key ? 2 : c23.y == key ? 3 : -1;
+        if (slot < 0) {
+            const int emp = c01.x == GASM_EMPTY64 ? 0 : c01.y == GASM_EMPTY64 ? 1 : c23.x == GASM_EMPTY64 ? 2 : c23.y == GASM_EMPTY64 ? 3 : -1;
+            if (emp < 0) { set = (set + 1) & (NSETS - 1); return false; }
+            const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&t_key[4 * set + emp]), (unsigned long long)GASM_EMPTY64,
+                                      (unsigned long long)key);
+            if (old == GASM_EMPTY64) atomicAdd(&s_tmp[4], 1u);
+            else if (old != key) return false;       // someone else took the slot: look at the set again
+            slot = emp;
         }
+        atomicAdd(&t_cnt[4 * set + slot], 1u);
+        return true;
+    };
+    auto insert = [&](u64 key) {
+        u32 set = hash64(key) >> (32 - LOG_SETS);
+        for (u32 probe = 0; probe < 8 * NSETS; ++probe) if (step(key, set)) return;
         s_tmp[5] = 1;
     };
     // 16-byte loads, four in flight per thread (the loop is latency-bound otherwise): head/tail singles, pairs between
@@ -371,23 +384,36 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys
             const u64 j = i + (u64)q * GASM_WG;
             v[q] = j < npairs ? kp[j] : make_ulonglong2(GASM_EMPTY64, GASM_EMPTY64);
         }
+        if ((dbg & 3) == 1) { u64 x = 0; for (int q = 0; q < 4; ++q) x ^= v[q].x ^ v[q].y; if (x == 0x1234567) s_tmp[6] = 1; continue; }
         if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { s_tmp[5] = 1; break; }
-        // first probes of all eight keys in flight together (one LDS round trip instead of eight); nearly every key
-        // is a repeat of one already in the table, so the hit path is the common one
-        u64 kx[8], cur[8];
-        u32 hx[8];
+        u64 kx[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { kx[2 * q] = v[q].x; kx[2 * q + 1] = v[q].y; }
+        // two batches of four keys: the four home sets are read together (8 x ds_read_b128 in flight), hits are counted,
+        // the few keys that are not done loop on their own
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            hx[q] = hash64(kx[q]) >> (32 - LOG_TBL);
-            cur[q] = __hip_atomic_load(&t_key[hx[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        for (int h = 0; h < 2; ++h) {
+            u32 set[4];
+            u64x2 c01[4], c23[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            if (kx[q] == GASM_EMPTY64) continue;
-            if (cur[q] == kx[q]) atomicAdd(&t_cnt[hx[q]], 1u);
-            else insert(kx[q]);
+            for (int q = 0; q < 4; ++q) {
+                set[q] = hash64(kx[4 * h + q]) >> (32 - LOG_SETS);
+                c01[q] = lds_load128(&t_key[4 * set[q]]);
+                c23[q] = lds_load128(&t_key[4 * set[q] + 2]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u64 key = kx[4 * h + q];
+                if (key == GASM_EMPTY64) continue;
+                const int slot = c01[q].x == key ? 0 : c01[q].y == key ? 1 : c23[q].x == key ? 2 : c23[q].y == key ? 3 : -1;
+                if (slot >= 0) atomicAdd(&t_cnt[4 * set[q] + slot], 1u);
+                else {
+                    u32 st = set[q];
+                    bool ok = false;
+                    for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = step(key, st);
+                    if (!ok) s_tmp[5] = 1;
+                }
+            }
         }
     }
     __syncthreads();
@@ -396,6 +422,7 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys
         return;
     }
     const u32 d = s_tmp[4];
+    if ((dbg & 3) == 1 || (dbg & 3) == 2) { if (threadIdx.x == 0) bucket_d[bucket] = d; return; }
     // ---- every thread pulls its slots (stride 256: conflict-free) into registers and bins them
     const int bshift = low_bits > (LOG_TBL - 2) ? low_bits - (LOG_TBL - 2) : 0;
     u64 rk[SL];
@@ -469,8 +496,8 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys
     for (u32 i = threadIdx.x; i < d; i += GASM_WG) { keys[beg + i] = t_key[i]; mult[beg + i] = t_cnt[i]; }
     if (threadIdx.x == 0) bucket_d[bucket] = d;
 }
-template __global__ void k_bucket_dedup<4096>(u64*, u32*, const u64*, u32*, u32*, int);
-template __global__ void k_bucket_dedup<2048>(u64*, u32*, const u64*, u32*, u32*, int);
+template __global__ void k_bucket_dedup<4096>(u64*, u32*, const u64*, u32*, u32*, int, int);
+template __global__ void k_bucket_dedup<2048>(u64*, u32*, const u64*, u32*, u32*, int, int);
 
 // Gather the per-bucket distinct runs into the dense per-segment arrays.
 __global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const u64* __restrict__ keys, const u32* __restrict__ mult,

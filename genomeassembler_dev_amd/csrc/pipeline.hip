@@ -193,7 +193,7 @@ PathSet DevPaths::view() const {
 void DevPaths::release() { d_words.release(); d_p_off.release(); d_seg_path_off.release(); d_seg_base_off.release(); }
 
 void BuildState::release() {
-    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_tcnt, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
+    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_tcnt, &d_cube, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
                     &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_seg_cbases, &d_seg_cstart,
                     &d_seg_bstart, &d_c_off, &d_contig_ascii})
         b->release();
@@ -252,12 +252,15 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     bool small_tbl;
     {
         const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
-        small_tbl = (dest >> bbits) <= 800;
+        small_tbl = (dest >> bbits) <= 640;   // <= ~30 % load of the 2048-slot table (4-slot sets overflow rarely)
+        if (getenv("GASM_DEDUP_TBL")) small_tbl = atoi(getenv("GASM_DEDUP_TBL")) == 2048;
     }
+    const int dbg_s = getenv("GASM_DBG_SCATTER") ? atoi(getenv("GASM_DBG_SCATTER")) : 0;   // tuning ablations (wrong results!)
+    const int dbg_d = getenv("GASM_DBG_DEDUP") ? atoi(getenv("GASM_DBG_DEDUP")) : 0;
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
     if (N == 0) {
@@ -279,32 +282,29 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         nbt = S * nb;
         GCHK(bs.d_hist.ensure((size_t)nbt * 4));
         GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 4));
+        GCHK(bs.d_cube.ensure((size_t)rd.n_tiles * nb * tr * orr * 4 * 2 + 64));
         GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
         GCHK(bs.d_dstart.ensure(((size_t)nbt + 2) * 4));
         HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 64, ctx->stream));
-        GLAUNCH(ctx, "k_tile_hist", k_tile_hist, dim3(grid_tiles), dim3(GASM_WG), nb * 4, rs, k, bbits, g, tr, rd.n_tiles,
-                bs.d_tcnt.as<u32>());
-        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(std::min(1024u, std::max(64u, nb))), 0, rs, bbits, bs.d_tcnt.as<u32>(),
-                bs.d_hist.as<u32>());
-        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
         const u32 rt = tr * orr;
-        const size_t lds = (size_t)GASM_KT * GASM_WG * 10 + (size_t)nb * (16 + 32 * rt + 64);
-        if (lds > 160 * 1024) { gasm_set_error("scatter tile does not fit LDS (%zu bytes)", lds); return GASM_ERR_CAPACITY; }
-        if (rt == 4) {
-            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<4>, dim3(grid_tiles), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_keys.as<u64>());
-        } else {
-            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<0>, dim3(grid_tiles), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_keys.as<u64>());
-        }
+        if ((size_t)rt * 4 * nb * 4 > 160 * 1024) { gasm_set_error("count cube does not fit LDS"); return GASM_ERR_CAPACITY; }
+        GLAUNCH(ctx, "k_tile_hist", k_tile_hist, dim3(grid_tiles), dim3(GASM_WG), (size_t)rt * 4 * nb * 4, rs, k, bbits, g, tr, orr, rd.n_tiles,
+                bs.d_cube.as<u16>());
+        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(std::min(1024u, std::max(64u, nb))), 0, rs, bbits, rt * 4, bs.d_cube.as<u16>(),
+                bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
+        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
+        const size_t lds = (size_t)GASM_KT * 64 * 4 * 8 + (size_t)nb * 48 + 64;
+        const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 64));
+        GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter, dim3(grid_scatter), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
+                bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), dbg_s);
         if (small_tbl) {
             GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup<2048>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), 2 * k - bbits);
+                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), 2 * k - bbits, dbg_d);
         } else {
             GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup<4096>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), 2 * k - bbits);
+                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), 2 * k - bbits, dbg_d);
         }
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt);
         bs.h_dstart.resize((size_t)nbt + 1);
