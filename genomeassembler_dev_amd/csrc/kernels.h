@@ -19,9 +19,35 @@ struct ReadSet {
 struct GraphView {
     const u64* dk_key;   // D_total keys, sorted inside each segment
     const u32* dstart;   // n_segments * 2^bbits + 1
+    const u16* fdir;     // fine directory: per bucket 2^fbits + 1 offsets (relative to the bucket) of the key bins the
+                         // de-duplication kernel sorted by — the next fbits key bits below the bucket prefix
     int k;
     int bbits;
+    int fbits;
 };
+
+// Lower bound of k-mer t among the distinct k-mers of segment `seg`: bucket by the first bbits bits, bin by the next
+// fbits bits (about 1.5 keys per bin), then a search inside the bin.  *bucket_hi = end of the bucket: the result is a
+// valid lower bound inside [bucket start, *bucket_hi].
+__device__ __forceinline__ u32 graph_lower_bound(const GraphView& gv, u32 seg, u64 t, u32* bucket_hi) {
+    const u32 nb = 1u << gv.bbits;
+    const int low = 2 * gv.k - gv.bbits;
+    const u32 gb = seg * nb + (gv.bbits ? (u32)(t >> low) : 0u);
+    const u32 base = gv.dstart[gb];
+    *bucket_hi = gv.dstart[gb + 1];
+    const int bshift = low > gv.fbits ? low - gv.fbits : 0;
+    const u32 nbin = 1u << gv.fbits;
+    const u16* f = gv.fdir + (u64)gb * (nbin + 1) + ((u32)(t >> bshift) & (nbin - 1));
+    u32 lo = base + f[0];
+    u32 hi = base + f[1];
+    while (hi - lo > 4) {                          // only skewed bins are this long
+        const u32 m = (lo + hi) >> 1;
+        if (gv.dk_key[m] < t) lo = m + 1;
+        else hi = m;
+    }
+    while (lo < hi && gv.dk_key[lo] < t) ++lo;     // bins usually hold one or two keys
+    return lo;
+}
 
 // Paths (contigs or caller-supplied sequences) of all segments, packed, for scoring.
 struct PathSet {
@@ -45,13 +71,16 @@ __global__ void k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u3
                                  const u32* toff, const u16* cube, u64* keys, int dbg);
 #define GASM_RT_MAX 16      // rounds (read groups x offset rounds) one scatter tile may hold
 template <int TBL>
-__global__ void k_bucket_dedup(u64* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, int low_bits, int dbg);
+__global__ void k_bucket_dedup(u64* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits,
+                               int dbg, unsigned long long* stamps);
 __global__ void k_bucket_gather(const u64* keys, const u32* mult, const u64* bstart, const u32* dstart, u64* dk_key,
                                 u32* dk_cnt);
 __global__ void k_node_flags(GraphView gv, u8* eflag);
 __global__ void k_edge_next(GraphView gv, const u8* eflag, u32* nxt, u64* link);
 __global__ void k_link_jump(u64* link, u32 n_edges);
 __global__ void k_link_rank_seg(GraphView gv, u64* link, int max_rounds);
+__global__ void k_rank_walk(GraphView gv, const u8* eflag, const u32* nxt, u64* link, u32 n_edges, int phase);
+__global__ void k_rank_anchors(GraphView gv, const u8* eflag, u64* link, int max_rounds);
 __global__ void k_chain_len(const u8* eflag, const u32* nxt, const u64* link, u32* clen, u32 n_edges);
 __global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u32* e_cid, u64* e_coff, u32* seg_ncontig,
                               u64* seg_cbases);
@@ -67,8 +96,11 @@ struct SeedTable {
 };
 __global__ void k_seed_insert(PathSet ps, SeedTable st, const u64* seg_base_off, int w);
 __global__ void k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, u32* poscnt);
-__global__ void k_read_match_graph(ReadSet rs, GraphView gv, const u8* eflag, const u64* link, const u32* e_cid, PathSet ps,
-                                   u32* poscnt);
+__global__ void k_score_reads_graph(ReadSet rs, GraphView gv, const u64* link, const u32* e_cid, PathSet ps, const long long* dfix,
+                                    int kmer, u32 reads_per_wg, u32* cnt, unsigned long long* sum);
+__global__ void k_score_finish(PathSet ps, const u32* cnt, const unsigned long long* sum, const long long* dfix, const u64* seg_empty,
+                               int kmer, double inv_scale, double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,
+                               int32_t* seq_len, u32 n_paths);
 __global__ void k_path_reduce(PathSet ps, const u32* poscnt, const u32* extra, const double* dprob, int kmer,
                               double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,
                               int32_t* seq_len, u32 n_paths);

@@ -142,6 +142,8 @@ __global__ void __launch_bounds__(GASM_WG) k_tile_hist(ReadSet rs, int k, int bb
 
 // Per segment and bucket: tile totals from the cube, their running sum toff[tile * nb + b] (offset of the tile inside
 // its (segment,bucket) range) and the bucket total hist[seg * nb + b].  One workgroup per segment, thread = bucket.
+// Each tile's run is rounded up to 16 k-mers = one 128-byte line, so no cache line is shared by two workgroups: partial
+// line writes from different L2s cost more than half the store bandwidth (measured: 2.1 vs 5.9 TB/s).
 __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 rt4, const u16* __restrict__ cube,
                                                     u32* __restrict__ toff, u32* __restrict__ hist) {
     const u32 nb = 1u << bbits, seg = blockIdx.x;
@@ -160,7 +162,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 r
                 for (u32 e = 0; e < rt4; ++e) tot += c[e];
             }
             toff[(u64)t * nb + b] = run;
-            run += tot;
+            run += (tot + 15u) & ~15u;      // every (tile, bucket) run starts on a 128-byte line (filler: see k_bucket_scatter)
         }
         hist[(u64)seg * nb + b] = run;
     }
@@ -232,6 +234,23 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, i
             const uint4 v0 = c4[0], v1 = c4[1];
             cw[0] = v0.x; cw[1] = v0.y; cw[2] = v0.z; cw[3] = v0.w; cw[4] = v1.x; cw[5] = v1.y; cw[6] = v1.z; cw[7] = v1.w;
             tbase = bstart[(u64)ti.seg * nb + ln] + toff[(u64)tile * nb + ln];
+        }
+        // filler behind the tile's run of every bucket, up to the next 128-byte line (the de-duplication skips it)
+        if (wv == 0) {
+            for (u32 b = ln; b < nb; b += 64) {
+                u32 tot = 0;
+                u64 base;
+                if (fast) {
+#pragma unroll
+                    for (u32 e = 0; e < 8; ++e) tot += (cw[e] & 0xFFFF) + (cw[e] >> 16);
+                    base = tbase;
+                } else {
+                    const u16* c = cube + ((u64)tile * nb + b) * rt4;
+                    for (u32 e = 0; e < rt4; ++e) tot += c[e];
+                    base = bstart[(u64)ti.seg * nb + b] + toff[(u64)tile * nb + b];
+                }
+                for (u32 i = tot; i < ((tot + 15u) & ~15u); ++i) keys[base + i] = GASM_EMPTY64;
+            }
         }
         u32 run_before = 0;   // fast path: k-mers of this lane's bucket in earlier rounds (all waves)
         for (u32 q = 0; q < rt; ++q) {
@@ -320,11 +339,25 @@ __device__ __forceinline__ u64x2 lds_load128(const u64* p) {
     return *reinterpret_cast<const u64x2*>(p);
 }
 
+// launch bounds: the 2048-slot variant fits five workgroups per CU in LDS (5 waves per SIMD: <= 96 registers), the
+// 4096-slot variant three (<= 168); without the bound the compiler used 169 and halved the residency
 template <int TBL>
-__global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys, u32* __restrict__ mult,
+__global__ void __launch_bounds__(GASM_WG, TBL == 2048 ? 5 : 3) k_bucket_dedup(u64* __restrict__ keys, u32* __restrict__ mult,
                                                           const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
-                                                          u32* __restrict__ overflow, int low_bits, int dbg) {
+                                                          u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg,
+                                                          unsigned long long* __restrict__ stamps) {
     constexpr int LIMIT = TBL / 16 * 11;
+    // diagnostic only (stamps == nullptr in production): per-phase wave-0 cycle totals, summed over workgroups
+    unsigned long long tph = stamps ? wall_clock64() : 0ull;
+    if (stamps && threadIdx.x == 0) {
+        // per-workgroup trace behind the 8 phase totals: start tick, end tick, hardware id
+        stamps[8 + 3 * (u64)blockIdx.x] = tph;
+        stamps[8 + 3 * (u64)blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_REG_HW_ID
+                                              ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
+    }
+    auto phase = [&](int i) {
+        if (stamps && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&stamps[i], t - tph); tph = t; }
+    };
     constexpr int BINS = TBL / 4;
     constexpr int SL = TBL / GASM_WG;
     constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
@@ -341,6 +374,7 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys
     for (u32 i = threadIdx.x; i < BINS; i += GASM_WG) s_start[i] = 0;
     if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }  // [4] distinct so far, [5] overflow, [6] longest bin
     __syncthreads();
+    phase(0);
     // The table is TBL/4 sets of four slots (32 bytes).  A key lives in the first set with room, counted from its
     // home set; sets fill left to right.  One probe = the whole set (2 x ds_read_b128), so unless a home set has
     // overflowed (rare at <= 30 % load) a key is found in the first probe — which matters because a wave moves at the
@@ -372,12 +406,13 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys
     };
     // 16-byte loads, four in flight per thread (the loop is latency-bound otherwise): head/tail singles, pairs between
     const u64 a0 = (beg + 1) & ~1ull;
-    if (threadIdx.x == 0 && a0 > beg && n) insert(keys[beg]);
+    if (threadIdx.x == 0 && a0 > beg && n) { const u64 k0 = keys[beg]; if (k0 != GASM_EMPTY64) insert(k0); }
     const u64 first = a0 < end ? a0 : end;
     const u64 npairs = (end - first) >> 1;
-    if (threadIdx.x == 1 && ((end - first) & 1)) insert(keys[end - 1]);
+    if (threadIdx.x == 1 && ((end - first) & 1)) { const u64 k1 = keys[end - 1]; if (k1 != GASM_EMPTY64) insert(k1); }
     const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(keys + first);
     for (u64 i = threadIdx.x; i < npairs; i += 4 * GASM_WG) {
+        if (i == threadIdx.x + 4 * GASM_WG) phase(1);   // first iteration (table fill) done
         ulonglong2 v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -416,7 +451,9 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys
             }
         }
     }
+    phase(2);
     __syncthreads();
+    phase(3);
     if (s_tmp[5] || s_tmp[4] > (u32)LIMIT) {
         if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[bucket] = 0; }
         return;
@@ -442,7 +479,13 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys
         u32 tot;
         u32 ex = block_excl_scan<GASM_WG>(sum, s_tmp, &tot);
 #pragma unroll
-        for (int q = 0; q < PER; ++q) { s_start[threadIdx.x * PER + q] = ex; s_cur[threadIdx.x * PER + q] = ex; ex += c[q]; }
+        for (int q = 0; q < PER; ++q) {
+            s_start[threadIdx.x * PER + q] = ex;
+            s_cur[threadIdx.x * PER + q] = ex;
+            fdir[(u64)bucket * (BINS + 1) + threadIdx.x * PER + q] = (u16)ex;   // fine directory for the graph kernels
+            ex += c[q];
+        }
+        if (threadIdx.x == GASM_WG - 1) fdir[(u64)bucket * (BINS + 1) + BINS] = (u16)ex;
         if (mx > 1) atomicMax(&s_tmp[6], mx);
     }
     __syncthreads();
@@ -493,11 +536,14 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup(u64* __restrict__ keys
             }
         }
     }
+    phase(4);
     for (u32 i = threadIdx.x; i < d; i += GASM_WG) { keys[beg + i] = t_key[i]; mult[beg + i] = t_cnt[i]; }
     if (threadIdx.x == 0) bucket_d[bucket] = d;
+    phase(5);
+    if (stamps && threadIdx.x == 0) stamps[8 + 3 * (u64)blockIdx.x + 1] = wall_clock64();
 }
-template __global__ void k_bucket_dedup<4096>(u64*, u32*, const u64*, u32*, u32*, int, int);
-template __global__ void k_bucket_dedup<2048>(u64*, u32*, const u64*, u32*, u32*, int, int);
+template __global__ void k_bucket_dedup<4096>(u64*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
+template __global__ void k_bucket_dedup<2048>(u64*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
 
 // Gather the per-bucket distinct runs into the dense per-segment arrays.
 __global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const u64* __restrict__ keys, const u32* __restrict__ mult,
@@ -514,10 +560,8 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const u64* __restrict
 // u = key>>2 (x·M), target node v = key & mask (M·y).  blockIdx.y = segment.
 // ================================================================================================================
 __device__ __forceinline__ bool kmer_exists(const GraphView& gv, u32 seg, u64 t) {
-    const u32 nb = 1u << gv.bbits;
-    const u32 bkt = gv.bbits ? (u32)(t >> (2 * gv.k - gv.bbits)) : 0u;
-    const u32 lo = gv.dstart[seg * nb + bkt], hi = gv.dstart[seg * nb + bkt + 1];
-    const u32 j = lower_bound_dev<u64>(gv.dk_key, lo, hi, t);
+    u32 hi;
+    const u32 j = graph_lower_bound(gv, seg, t, &hi);
     return j < hi && gv.dk_key[j] == t;
 }
 
@@ -556,11 +600,9 @@ __global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, const u8* _
     const int sh = 2 * (gv.k - 1);
     const u64 v = sh ? (key & ((1ull << sh) - 1)) : 0ull;
     const u64 t = v << 2;  // smallest k-mer with prefix v
-    const u32 bkt = gv.bbits ? (u32)(t >> (2 * gv.k - gv.bbits)) : 0u;
-    const u32 blo = gv.dstart[seg * nb + bkt];
     // the run of v may continue into the next bucket only if bbits > 2(k-1), which the host never chooses
-    const u32 bhi = gv.dstart[seg * nb + bkt + 1];
-    const u32 j = lower_bound_dev<u64>(gv.dk_key, blo, bhi, t);
+    u32 bhi;
+    const u32 j = graph_lower_bound(gv, seg, t, &bhi);
     u32 n = GASM_NONE32;
     if (j < bhi && (gv.dk_key[j] >> 2) == v && !(eflag[j] & 1)) n = j;  // v has out-edges and is not branching
     nxt[i] = n;
@@ -623,6 +665,100 @@ __global__ void __launch_bounds__(1024) k_link_rank_seg(GraphView gv, u64* __res
                 else { nl = ((u64)a2 << 32) | (la[q] & GASM_LINK_DONE) | d; any = any || !(la[q] & GASM_LINK_DONE); }
                 __hip_atomic_store(&link[i], nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+        }
+        if (any) s_active = 1;
+        __syncthreads();
+        const bool go = s_active != 0;
+        __syncthreads();
+        if (!go) break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// List ranking by a ruling set (work O(D) instead of O(D log D)).  Anchors = chain heads + a pseudo-random eighth of
+// the edges.
+//   k_rank_walk phase 1: every anchor walks forward to the next anchor and leaves (itself, steps) there as that
+//                        anchor's ancestor link — gaps are ~8 edges, < 100 with overwhelming probability;
+//   k_rank_anchors     : pointer doubling over the anchors only (one workgroup per segment, the anchor list in LDS);
+//   k_rank_walk phase 3: every ranked anchor walks its gap again and writes (head, done, distance) on the edges in it.
+// Members of isolated cycles never get a done link, exactly as with plain pointer doubling.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_anchor(u32 i, u8 flag) { return (flag & 1) || ((i * 0x9E3779B1u) >> 29) == 0; }
+
+__global__ void __launch_bounds__(GASM_WG) k_rank_walk(GraphView gv, const u8* __restrict__ eflag, const u32* __restrict__ nxt,
+                                                       u64* __restrict__ link, u32 n_edges, int phase) {
+    const u32 i = blockIdx.x * GASM_WG + threadIdx.x;
+    if (i >= n_edges) return;
+    const u8 f = eflag[i];
+    if (!is_anchor(i, f)) return;
+    (void)gv;
+    if (phase == 1) {
+        u32 cur = i;
+        for (u32 steps = 1; steps <= n_edges; ++steps) {
+            const u32 n = nxt[cur];
+            if (n == GASM_NONE32) break;
+            if (is_anchor(n, eflag[n])) {     // n is never a head: heads are nobody's successor
+                link[n] = ((u64)i << 32) | ((f & 1) ? GASM_LINK_DONE : 0ull) | steps;
+                break;
+            }
+            cur = n;
+        }
+    } else {
+        const u64 l = link[i];
+        if ((u32)(l >> 32) == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;   // anchor on an isolated cycle
+        const u64 head = l & 0xFFFFFFFF00000000ull;
+        u32 d = (u32)l & 0x7FFFFFFFu;
+        u32 cur = i;
+        for (u32 steps = 1; steps <= n_edges; ++steps) {
+            const u32 n = nxt[cur];
+            if (n == GASM_NONE32 || is_anchor(n, eflag[n])) break;
+            ++d;
+            link[n] = head | GASM_LINK_DONE | d;
+            cur = n;
+        }
+    }
+}
+
+#define GASM_ANCHOR_CAP 12288
+__global__ void __launch_bounds__(1024) k_rank_anchors(GraphView gv, const u8* __restrict__ eflag, u64* __restrict__ link, int max_rounds) {
+    __shared__ u32 s_list[GASM_ANCHOR_CAP];
+    __shared__ u32 s_n, s_active;
+    const u32 seg = blockIdx.x;
+    const u32 nb = 1u << gv.bbits;
+    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
+    const u32 n = hi - lo;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // unranked anchors of this segment (heads are ranked already: their own ancestor, done)
+    for (u32 i = lo + threadIdx.x; i < hi; i += 1024) {
+        const u8 f = eflag[i];
+        if (!(f & 1) && is_anchor(i, f)) {
+            const u32 p = atomicAdd(&s_n, 1u);
+            if (p < GASM_ANCHOR_CAP) s_list[p] = i;
+        }
+    }
+    __syncthreads();
+    const u32 na = s_n;
+    const bool listed = na <= GASM_ANCHOR_CAP;     // else walk the whole segment every round
+    const u32 count = listed ? na : n;
+    for (int r = 0; r < max_rounds; ++r) {
+        if (threadIdx.x == 0) s_active = 0;
+        __syncthreads();
+        bool any = false;
+        for (u32 e = threadIdx.x; e < count; e += 1024) {
+            u32 i;
+            if (listed) i = s_list[e];
+            else { i = lo + e; const u8 f = eflag[i]; if ((f & 1) || !is_anchor(i, f)) continue; }
+            const u64 l = __hip_atomic_load(&link[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32 a = (u32)(l >> 32);
+            if (a == GASM_NONE32 || (l & GASM_LINK_DONE)) continue;
+            const u64 la = __hip_atomic_load(&link[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u32 a2 = (u32)(la >> 32);
+            const u32 d = ((u32)l & 0x7FFFFFFFu) + ((u32)la & 0x7FFFFFFFu);
+            u64 nl;
+            if (a2 == GASM_NONE32 || d > n) nl = ~0ull;            // on an isolated cycle
+            else { nl = ((u64)a2 << 32) | (la & GASM_LINK_DONE) | d; any = any || !(la & GASM_LINK_DONE); }
+            __hip_atomic_store(&link[i], nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (any) s_active = 1;
         __syncthreads();

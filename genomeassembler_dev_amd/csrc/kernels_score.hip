@@ -99,40 +99,107 @@ __global__ void __launch_bounds__(GASM_WG) k_read_match(ReadSet rs, PathSet ps, 
 }
 
 // Batch path: the paths are the contigs of the same build, so the index already exists.  A read of length >= k starts
-// with a k-mer; that k-mer is one distinct edge (2-level search in the sorted list); list ranking left (head, distance)
-// on every edge, i.e. the contig and the offset of the k-mer inside it.  Every k-mer lies on at most one contig, once,
-// so this is the only place the read can occur: compare the rest of the read there (lib/DeNovoAssembler.cpp:360).
-__global__ void __launch_bounds__(GASM_WG) k_read_match_graph(ReadSet rs, GraphView gv, const u8* __restrict__ eflag,
-                                                              const u64* __restrict__ link, const u32* __restrict__ e_cid,
-                                                              PathSet ps, u32* __restrict__ poscnt) {
-    const u32 seg = blockIdx.y;
-    const u64 r = rs.seg_read_off[seg] + (u64)blockIdx.x * GASM_WG + threadIdx.x;
-    if (r >= rs.seg_read_off[seg + 1]) return;
+// with a k-mer; that k-mer is one distinct edge (bucket, bin, a one-or-two-key search); list ranking left (head,
+// distance) on every edge, i.e. the contig and the offset of the k-mer inside it.  Every k-mer lies on at most one
+// contig, once, so this is the only place the read can occur: compare the rest of the read there
+// (lib/DeNovoAssembler.cpp:360).
+// Returns the global base position of the hit, or ~0 when the read matches no contig.
+__device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& gv, const u64* __restrict__ link,
+                                           const u32* __restrict__ e_cid, const PathSet& ps, u32 seg, u64 r) {
     u64 p0; u32 len;
     if (rs.fixed_len) { p0 = r * rs.fixed_len; len = rs.fixed_len; }
     else { p0 = rs.read_off[r]; len = (u32)(rs.read_off[r + 1] - p0); }
-    if (len < (u32)gv.k) return;
+    if (len < (u32)gv.k) return ~0ull;
     const u64 key = kmer_at(rs.words, p0, gv.k);
-    const u32 nb = 1u << gv.bbits;
-    const u32 bkt = gv.bbits ? (u32)(key >> (2 * gv.k - gv.bbits)) : 0u;
-    const u32 lo = gv.dstart[seg * nb + bkt], hi = gv.dstart[seg * nb + bkt + 1];
-    const u32 e = lower_bound_dev<u64>(gv.dk_key, lo, hi, key);
-    if (e >= hi || gv.dk_key[e] != key) return;
+    u32 hi;
+    const u32 e = graph_lower_bound(gv, seg, key, &hi);
+    if (e >= hi || gv.dk_key[e] != key) return ~0ull;
     const u64 l = link[e];
     const u32 a = (u32)(l >> 32);
-    if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;   // on an isolated cycle: part of no contig
-    (void)eflag;
+    if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return ~0ull;   // on an isolated cycle: part of no contig
     const u32 c = e_cid[a];
-    const u64 pb = ps.p_off[c];
-    const u64 g = pb + ((u32)l & 0x7FFFFFFFu);
-    if (g + len > ps.p_off[c + 1]) return;
+    const u64 g = ps.p_off[c] + ((u32)l & 0x7FFFFFFFu);
+    if (g + len > ps.p_off[c + 1]) return ~0ull;
     bool same = true;
     for (u32 o = 0; o < len && same; o += 32) {
         const u32 nbase = len - o < 32 ? len - o : 32;
         const u64 x = window32(rs.words, p0 + o), y = window32(ps.words, g + o);
         same = ((x ^ y) >> (64 - 2 * nbase)) == 0;
     }
-    if (same) atomicAdd(&poscnt[g], 1u);
+    return same ? g : ~0ull;
+}
+
+// Batch scoring without position counters.  bp_score of a path = sum over the reads that occur in it of
+// prob(window(hit position)) (lib/DeNovoAssembler.cpp:389-413 sums count x prob per table row: the same terms grouped
+// differently).  Each read adds 1 to its path's count and round(prob * 2^fx_shift) to its path's 64-bit fixed-point sum:
+// integer additions commute, so the result does not depend on the order the reads arrive in (bit-reproducible without a
+// fixed reduction tree).  A workgroup keeps the accumulators of its segment's paths in LDS (ds_add_u32 / ds_add_u64) and
+// flushes the non-zero ones with global atomics at the end; segments with more paths than fit go to global atomics
+// directly.  blockIdx.y = segment, blockIdx.x = slice of the segment's reads.
+#define GASM_SCORE_PATH_CAP 6144
+__global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, GraphView gv, const u64* __restrict__ link,
+                                                               const u32* __restrict__ e_cid, PathSet ps,
+                                                               const long long* __restrict__ dfix, int kmer, u32 reads_per_wg,
+                                                               u32* __restrict__ cnt, unsigned long long* __restrict__ sum) {
+    __shared__ unsigned long long s_sum[GASM_SCORE_PATH_CAP];
+    __shared__ u32 s_cnt[GASM_SCORE_PATH_CAP];
+    const u32 seg = blockIdx.y;
+    const u64 r0 = rs.seg_read_off[seg] + (u64)blockIdx.x * reads_per_wg;
+    const u64 rseg_end = rs.seg_read_off[seg + 1];
+    if (r0 >= rseg_end) return;
+    const u64 r1 = r0 + reads_per_wg < rseg_end ? r0 + reads_per_wg : rseg_end;
+    const u32 pfirst = ps.seg_path_off[seg], np = ps.seg_path_off[seg + 1] - pfirst;
+    const bool in_lds = np <= GASM_SCORE_PATH_CAP;
+    if (in_lds) for (u32 i = threadIdx.x; i < np; i += GASM_WG) { s_sum[i] = 0; s_cnt[i] = 0; }
+    __syncthreads();
+    for (u64 r = r0 + threadIdx.x; r < r1; r += GASM_WG) {
+        const u64 g = graph_match(rs, gv, link, e_cid, ps, seg, r);
+        if (g == ~0ull) continue;
+        // path of the hit: the contig list of the segment is short; upper_seg is a binary search over its offsets
+        const u32 c = pfirst + upper_seg<u64>(ps.p_off + pfirst, np, g);
+        const u64 pb = ps.p_off[c];
+        const u32 plen = (u32)(ps.p_off[c + 1] - pb);
+        u32 idx;
+        long long fx = 0;
+        if (break_window(ps.words, pb, plen, (u32)(g - pb), kmer, &idx)) fx = dfix[idx];
+        if (in_lds) { atomicAdd(&s_cnt[c - pfirst], 1u); atomicAdd(&s_sum[c - pfirst], (unsigned long long)fx); }
+        else { atomicAdd(&cnt[c], 1u); atomicAdd(&sum[c], (unsigned long long)fx); }
+    }
+    __syncthreads();
+    if (in_lds) for (u32 i = threadIdx.x; i < np; i += GASM_WG) {
+        const u32 c = s_cnt[i];
+        if (c) { atomicAdd(&cnt[pfirst + i], c); atomicAdd(&sum[pfirst + i], s_sum[i]); }
+    }
+}
+
+// Fixed-point sums -> the reference's per-path numbers.  `seg_empty`: empty reads of the path's segment, each a hit at
+// position 0 of every path (std::string::find("") == 0).
+__global__ void __launch_bounds__(GASM_WG) k_score_finish(PathSet ps, const u32* __restrict__ cnt, const unsigned long long* __restrict__ sum,
+                                                          const long long* __restrict__ dfix, const u64* __restrict__ seg_empty,
+                                                          int kmer, double inv_scale, double* __restrict__ bp_score,
+                                                          double* __restrict__ norm_freq, double* __restrict__ norm_len,
+                                                          int32_t* __restrict__ kmer_breaks, int32_t* __restrict__ seq_len, u32 n_paths) {
+    const u32 p = blockIdx.x * GASM_WG + threadIdx.x;
+    if (p >= n_paths) return;
+    const u64 pb = ps.p_off[p];
+    const u32 len = (u32)(ps.p_off[p + 1] - pb);
+    u32 tot = cnt[p];
+    long long fs = (long long)sum[p];
+    if (seg_empty) {
+        const u32 seg = upper_seg<u32>(ps.seg_path_off, ps.n_segments, p);
+        const u32 e = (u32)seg_empty[seg];
+        if (e) {
+            u32 idx;
+            tot += e;
+            if (break_window(ps.words, pb, len, 0, kmer, &idx)) fs += (long long)e * dfix[idx];
+        }
+    }
+    const double s1 = (double)fs * inv_scale;
+    bp_score[p] = s1;
+    norm_freq[p] = tot ? s1 / (double)tot : 0.0;
+    norm_len[p] = s1 / (double)(int32_t)len;
+    kmer_breaks[p] = (int32_t)tot;
+    seq_len[p] = (int32_t)len;
 }
 
 __device__ __forceinline__ u32 wave_sum_u32(u32 v) {
@@ -147,24 +214,30 @@ __device__ __forceinline__ double wave_sum_fixed(double v) {
     return v;
 }
 
-// One wave per path.  First the integer total of the path's position counters (= kmer_breaks; `extra` holds what
-// empty reads add to empty paths), then lane l sums positions l, l+64, ... in order and the 64 partials are combined
-// by a fixed butterfly.
+// One workgroup per path.  First the integer total of the path's position counters (= kmer_breaks; `extra` holds what
+// empty reads add to empty paths), then thread t sums positions t, t+256, ... in order, the 64 partials of a wave are
+// combined by a fixed butterfly and the four wave sums are added in wave order: a fixed summation order, so scores are
+// bit-reproducible.
 __global__ void __launch_bounds__(GASM_WG) k_path_reduce(PathSet ps, const u32* __restrict__ poscnt, const u32* __restrict__ extra,
                                                          const double* __restrict__ dprob, int kmer, double* __restrict__ bp_score,
                                                          double* __restrict__ norm_freq, double* __restrict__ norm_len,
                                                          int32_t* __restrict__ kmer_breaks, int32_t* __restrict__ seq_len, u32 n_paths) {
-    const u32 p = blockIdx.x * (GASM_WG / 64) + (threadIdx.x >> 6);
+    __shared__ u32 s_t[4];
+    __shared__ double s_a[4], s_b[4];
+    const u32 p = blockIdx.x;
     if (p >= n_paths) return;
-    const u32 lane = threadIdx.x & 63;
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u64 pb = ps.p_off[p];
     const u32 len = (u32)(ps.p_off[p + 1] - pb);
     u32 tsum = 0;
-    for (u32 j = lane; j < len; j += 64) tsum += poscnt[pb + j];
-    const u32 tot = wave_sum_u32(tsum) + extra[p];
+    for (u32 j = threadIdx.x; j < len; j += GASM_WG) tsum += poscnt[pb + j];
+    tsum = wave_sum_u32(tsum);
+    if (lane == 0) s_t[wv] = tsum;
+    __syncthreads();
+    const u32 tot = s_t[0] + s_t[1] + s_t[2] + s_t[3] + extra[p];
     const double dtot = (double)tot;
     double s1 = 0.0, s2 = 0.0;
-    for (u32 j = lane; j < len; j += 64) {
+    for (u32 j = threadIdx.x; j < len; j += GASM_WG) {
         const u32 c = poscnt[pb + j];
         if (c) {
             u32 idx;
@@ -177,10 +250,14 @@ __global__ void __launch_bounds__(GASM_WG) k_path_reduce(PathSet ps, const u32* 
     }
     s1 = wave_sum_fixed(s1);
     s2 = wave_sum_fixed(s2);
-    if (lane == 0) {
-        bp_score[p] = s1;
-        norm_freq[p] = s2;
-        norm_len[p] = s1 / (double)(int32_t)len;
+    if (lane == 0) { s_a[wv] = s1; s_b[wv] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double a = ((s_a[0] + s_a[1]) + s_a[2]) + s_a[3];
+        const double b = ((s_b[0] + s_b[1]) + s_b[2]) + s_b[3];
+        bp_score[p] = a;
+        norm_freq[p] = b;
+        norm_len[p] = a / (double)(int32_t)len;
         kmer_breaks[p] = (int32_t)tot;
         seq_len[p] = (int32_t)len;
     }

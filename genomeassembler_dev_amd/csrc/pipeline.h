@@ -48,14 +48,14 @@ struct DevPaths {
 };
 
 struct BuildState {
-    int k = 0, bbits = 0;
+    int k = 0, bbits = 0, fbits = 9;
     u64 n_kmers = 0;
     u32 d_total = 0, n_contigs = 0;
     u64 contig_bases = 0;
     std::vector<u32> h_dstart;              // n_segments*nb+1
     std::vector<u32> h_seg_cstart;          // n_segments+1
     std::vector<u64> h_seg_bstart;          // n_segments+1
-    DBuf d_keys, d_mult, d_hist, d_tcnt, d_cube, d_bstart, d_cursor, d_bucket_d, d_dstart, d_flags;
+    DBuf d_keys, d_mult, d_hist, d_tcnt, d_cube, d_fdir, d_bstart, d_cursor, d_bucket_d, d_dstart, d_flags;
     DBuf d_dk_key, d_dk_cnt, d_eflag, d_nxt, d_link, d_clen, d_ecid, d_ecoff;
     DBuf d_seg_cbases, d_seg_cstart, d_seg_bstart, d_c_off, d_contig_ascii;
     // host copies filled by fetch
@@ -68,15 +68,18 @@ struct BuildState {
 
 struct ScoreTable {
     // direct-address tables over ACGT strings of length 1..8 (87 380 rows)
-    DBuf d_prob, d_row;
+    DBuf d_prob, d_row, d_fix;
+    std::vector<double> h_prob;   // direct-address table as uploaded
+    int fix_shift = -1;           // d_fix = round(prob * 2^fix_shift), -1 = not built
     u32 n_table = 0;
+    int set_fixed(gasm_ctx* ctx, u64 max_terms);
     int set(gasm_ctx* ctx, const char* bp_kmer, const u64* bp_off, u64 n_table, const double* bp_prob);
     int set_standard(gasm_ctx* ctx, const double* table69904);
     void release();
 };
 
 struct ScoreState {
-    DBuf d_tbl_off, d_seed, d_gpos, d_poscnt, d_total, d_out_f64, d_out_i32, d_freq, d_pd_off, d_pd, d_seg_empty;
+    DBuf d_tbl_off, d_seed, d_gpos, d_poscnt, d_total, d_out_f64, d_out_i32, d_freq, d_pd_off, d_pd, d_seg_empty, d_fxsum;
     std::vector<u64> h_toff;
     u32 n_paths = 0, n_table = 0;
     bool want_freq = false, want_pd = false, launched = false;

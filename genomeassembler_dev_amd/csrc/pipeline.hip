@@ -3,6 +3,7 @@
 #include "pipeline.h"
 
 #include <algorithm>
+#include <cmath>
 
 // ---------------------------------------------------------------------------------------------------------------
 // small local kernels
@@ -193,14 +194,14 @@ PathSet DevPaths::view() const {
 void DevPaths::release() { d_words.release(); d_p_off.release(); d_seg_path_off.release(); d_seg_base_off.release(); }
 
 void BuildState::release() {
-    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_tcnt, &d_cube, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
+    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_tcnt, &d_cube, &d_fdir, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
                     &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_seg_cbases, &d_seg_cstart,
                     &d_seg_bstart, &d_c_off, &d_contig_ascii})
         b->release();
 }
 
 void ScoreState::release() {
-    for (DBuf* b : {&d_tbl_off, &d_seed, &d_gpos, &d_poscnt, &d_total, &d_out_f64, &d_out_i32, &d_freq, &d_pd_off, &d_pd, &d_seg_empty}) b->release();
+    for (DBuf* b : {&d_tbl_off, &d_seed, &d_gpos, &d_poscnt, &d_total, &d_out_f64, &d_out_i32, &d_freq, &d_pd_off, &d_pd, &d_seg_empty, &d_fxsum}) b->release();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -239,12 +240,12 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     if (orr > GASM_RT_MAX) { gasm_set_error("reads longer than %u bases are not supported", 64u * GASM_KT * GASM_RT_MAX); return GASM_ERR_CAPACITY; }
     const u32 tr = orr == 1 ? 4u : 1u;
     GCHK(rd.set_tiles(ctx, ipt * tr));
-    // bucket bits: aim at ~1400 distinct k-mers per bucket (the LDS table takes 2816)
+    // bucket bits: aim at <= ~900 distinct k-mers per bucket (2048-slot LDS table in 4-slot sets, limit 1408)
     const int bb_cap = std::min(10, 2 * (k - 1));
     int bbits = 0;
     {
         const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
-        while (bbits < bb_cap && (dest >> bbits) > 1400) ++bbits;
+        while (bbits < bb_cap && (dest >> bbits) > 900) ++bbits;
     }
     GCHK(bs.d_flags.ensure(64));
     bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
@@ -252,7 +253,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     bool small_tbl;
     {
         const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
-        small_tbl = (dest >> bbits) <= 640;   // <= ~30 % load of the 2048-slot table (4-slot sets overflow rarely)
+        small_tbl = (dest >> bbits) <= 900;   // else the 4096-slot table (fewer workgroups per CU)
         if (getenv("GASM_DEDUP_TBL")) small_tbl = atoi(getenv("GASM_DEDUP_TBL")) == 2048;
     }
     const int dbg_s = getenv("GASM_DBG_SCATTER") ? atoi(getenv("GASM_DBG_SCATTER")) : 0;   // tuning ablations (wrong results!)
@@ -272,8 +273,8 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         HIPCHK(hipStreamSynchronize(ctx->stream));
         return GASM_OK;
     }
-    GCHK(bs.d_keys.ensure(N * 8));
-    GCHK(bs.d_mult.ensure(N * 4));
+    // every (tile, bucket) run is padded to a multiple of 16 keys: room for the filler (bucket count fixed below)
+    const u64 n_pad_max = N + 16ull * rd.n_tiles * (1ull << bb_cap);
     const ReadSet rs = rd.view();
     const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * 16);
     u32 nbt = 0;
@@ -282,6 +283,11 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         nbt = S * nb;
         GCHK(bs.d_hist.ensure((size_t)nbt * 4));
         GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 4));
+        {
+            const u64 n_alloc = std::min<u64>(n_pad_max, N + 16ull * rd.n_tiles * nb);
+            GCHK(bs.d_keys.ensure(n_alloc * 8));
+            GCHK(bs.d_mult.ensure(n_alloc * 4));
+        }
         GCHK(bs.d_cube.ensure((size_t)rd.n_tiles * nb * tr * orr * 4 * 2 + 64));
         GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
@@ -299,12 +305,36 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 64));
         GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter, dim3(grid_scatter), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
                 bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), dbg_s);
+        unsigned long long* d_stamps = nullptr;
+        static DBuf stamp_buf;
+        if (getenv("GASM_DBG_STAMPS")) {   // diagnostic: per-phase cycle totals of k_bucket_dedup to stderr
+            int o1 = 0, o2 = 0, o3 = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_bucket_dedup<2048>, GASM_WG, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_bucket_dedup<4096>, GASM_WG, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, k_bucket_scatter, GASM_WG, (size_t)GASM_KT * 64 * 4 * 8 + (size_t)nb * 48 + 64);
+            fprintf(stderr, "[occupancy API] dedup<2048> %d  dedup<4096> %d  scatter %d blocks/CU\n", o1, o2, o3);
+            GCHK(stamp_buf.ensure(64 + (size_t)nbt * 24));
+            HIPCHK(hipMemsetAsync(stamp_buf.p, 0, 64 + (size_t)nbt * 24, ctx->stream));
+            d_stamps = stamp_buf.as<unsigned long long>();
+        }
+        bs.fbits = small_tbl ? 9 : 10;   // bins of the de-duplication kernel's counting sort = TBL / 4
+        GCHK(bs.d_fdir.ensure((size_t)nbt * ((1u << bs.fbits) + 1) * 2));
+        HIPCHK(hipMemsetAsync(bs.d_fdir.p, 0, (size_t)nbt * ((1u << bs.fbits) + 1) * 2, ctx->stream));
         if (small_tbl) {
             GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup<2048>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), 2 * k - bbits, dbg_d);
+                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
         } else {
             GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup<4096>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), 2 * k - bbits, dbg_d);
+                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+        }
+        if (d_stamps) {
+            std::vector<unsigned long long> hv(8 + (size_t)nbt * 3);
+            HIPCHK(hipMemcpyAsync(hv.data(), d_stamps, hv.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            const unsigned long long* h = hv.data();
+            if (FILE* f = fopen(getenv("GASM_DBG_STAMPS"), "wb")) { fwrite(hv.data(), 8, hv.size(), f); fclose(f); }
+            fprintf(stderr, "[dedup stamps, 100 MHz ticks per workgroup] init %.1f  first-iter %.1f  stream %.1f  barrier %.1f  order %.1f  writeback %.1f\n",
+                    (double)h[0] / nbt, (double)h[1] / nbt, (double)h[2] / nbt, (double)h[3] / nbt, (double)h[4] / nbt, (double)h[5] / nbt);
         }
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt);
         bs.h_dstart.resize((size_t)nbt + 1);
@@ -350,8 +380,10 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     GraphView gv;
     gv.dk_key = bs.d_dk_key.as<u64>();
     gv.dstart = bs.d_dstart.as<u32>();
+    gv.fdir = bs.d_fdir.as<u16>();
     gv.k = k;
     gv.bbits = bbits;
+    gv.fbits = bs.fbits;
     const dim3 grid_seg(ceil_div_u64(maxD, GASM_WG), S);
     const dim3 grid_all(ceil_div_u64(D, GASM_WG));
     GLAUNCH(ctx, "k_node_flags", k_node_flags, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>());
@@ -359,7 +391,14 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     int rounds = 1;
     while ((1ull << rounds) < (u64)maxD) ++rounds;
     rounds += 1;
-    if (maxD <= (1u << 18)) {
+    const int rank_mode = getenv("GASM_RANK_MODE") ? atoi(getenv("GASM_RANK_MODE")) : 1;
+    if (rank_mode == 2 && maxD <= (1u << 22)) {
+        // ruling set: anchors walk to the next anchor, anchors are ranked by pointer doubling inside one workgroup per
+        // segment, anchors walk again and rank the edges between them
+        GLAUNCH(ctx, "k_rank_walk", k_rank_walk, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>(), D, 1);
+        GLAUNCH(ctx, "k_rank_anchors", k_rank_anchors, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), rounds + 1);
+        GLAUNCH(ctx, "k_rank_walk", k_rank_walk, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>(), D, 3);
+    } else if (maxD <= (1u << 18)) {
         // one workgroup per segment runs every round (early exit); enough for segments up to 256k distinct k-mers
         GLAUNCH(ctx, "k_link_rank_seg", k_link_rank_seg, dim3(S), dim3(1024), 0, gv, bs.d_link.as<u64>(), rounds + 1);
     } else {
@@ -497,10 +536,33 @@ int ScoreTable::set_standard(gasm_ctx* ctx, const double* t) {
     GCHK(h2d(ctx, d_prob, prob.data(), prob.size() * 8));
     GCHK(h2d(ctx, d_row, row.data(), row.size() * 4));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    h_prob = prob;
+    fix_shift = -1;
     return GASM_OK;
 }
 
-void ScoreTable::release() { d_prob.release(); d_row.release(); }
+// 64-bit fixed-point copy of the table for the batch scorer: round(prob * 2^shift), shift chosen so that the sum over
+// `max_terms` reads cannot overflow 62 bits.
+int ScoreTable::set_fixed(gasm_ctx* ctx, u64 max_terms) {
+    double mx = 0;
+    for (double v : h_prob) mx = std::max(mx, std::fabs(v));
+    int shift = 62;
+    if (mx > 0) {
+        const double need = std::log2(mx * (double)std::max<u64>(1, max_terms));
+        shift = (int)std::floor(62.0 - need) - 1;
+    }
+    shift = std::max(0, std::min(1000, shift));
+    if (shift > 1000) shift = 1000;
+    if (shift == fix_shift) return GASM_OK;
+    std::vector<long long> fx(h_prob.size());
+    for (size_t i = 0; i < fx.size(); ++i) fx[i] = std::llrint(std::ldexp(h_prob[i], shift));
+    GCHK(h2d(ctx, d_fix, fx.data(), fx.size() * 8));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    fix_shift = shift;
+    return GASM_OK;
+}
+
+void ScoreTable::release() { d_prob.release(); d_row.release(); d_fix.release(); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // score: pipeline_score_launch queues everything on the stream; pipeline_score_fetch copies the results back.
@@ -521,21 +583,30 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
     GCHK(ss.d_total.ensure(((size_t)P + 1) * 4));
     GCHK(ss.d_out_f64.ensure(((size_t)P + 1) * 8 * 3));
     GCHK(ss.d_out_i32.ensure(((size_t)P + 1) * 4 * 2));
-    HIPCHK(hipMemsetAsync(ss.d_poscnt.p, 0, (TB + 1) * 4, ctx->stream));
+    const bool use_graph = graph && P && TB && rd.n_reads > rd.n_empty && rd.min_len >= (u32)graph->k && graph->d_total;
+    if (!use_graph) HIPCHK(hipMemsetAsync(ss.d_poscnt.p, 0, (TB + 1) * 4, ctx->stream));
     HIPCHK(hipMemsetAsync(ss.d_total.p, 0, ((size_t)P + 1) * 4, ctx->stream));
     const PathSet ps = dp.view();
     const int w = (int)std::min<u32>(32, rd.min_len);
-    if (graph && P && TB && rd.n_reads > rd.n_empty && rd.min_len >= (u32)graph->k && graph->d_total) {
-        // the paths are this build's contigs and every read holds a k-mer: the sorted edge list is the index
+    if (use_graph) {
+        // the paths are this build's contigs and every read holds a k-mer: the sorted edge list is the index, and the
+        // per-path sums are accumulated per read in fixed point (no position counters)
         GraphView gv;
         gv.dk_key = graph->d_dk_key.as<u64>();
         gv.dstart = graph->d_dstart.as<u32>();
+        gv.fdir = graph->d_fdir.as<u16>();
         gv.k = graph->k;
         gv.bbits = graph->bbits;
+        gv.fbits = graph->fbits;
         u64 max_reads = 0;
         for (u32 s = 0; s < S; ++s) max_reads = std::max(max_reads, rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]);
-        GLAUNCH(ctx, "k_read_match_graph", k_read_match_graph, dim3(ceil_div_u64(max_reads, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), gv,
-                graph->d_eflag.as<u8>(), graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, ss.d_poscnt.as<u32>());
+        GCHK(const_cast<ScoreTable&>(tb).set_fixed(ctx, max_reads));
+        GCHK(ss.d_fxsum.ensure(((size_t)P + 1) * 8));
+        HIPCHK(hipMemsetAsync(ss.d_fxsum.p, 0, ((size_t)P + 1) * 8, ctx->stream));
+        const u32 reads_per_wg = 2048;
+        GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph, dim3(ceil_div_u64(max_reads, reads_per_wg), S), dim3(GASM_WG), 0, rd.view(), gv,
+                graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, ss.d_total.as<u32>(),
+                ss.d_fxsum.as<unsigned long long>());
     } else if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
         // per-segment seed tables: power-of-two, at least twice the number of path positions
         std::vector<u64>& toff = ss.h_toff;
@@ -564,7 +635,7 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
                     dp.seg_base_off_dev(), w, ss.d_poscnt.as<u32>());
         }
     }
-    if (P && rd.n_empty) {
+    if (P && rd.n_empty && !use_graph) {
         GCHK(h2d(ctx, ss.d_seg_empty, rd.h_seg_empty.data(), (size_t)S * 8));
         u32 maxp = 0;
         for (u32 s = 0; s < S; ++s) maxp = std::max(maxp, dp.h_seg_path_off[s + 1] - dp.h_seg_path_off[s]);
@@ -576,8 +647,14 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
     double* o_nl = o_nf + (P + 1);
     int32_t* o_br = ss.d_out_i32.as<int32_t>();
     int32_t* o_ln = o_br + (P + 1);
-    if (P) {
-        GLAUNCH(ctx, "k_path_reduce", k_path_reduce, dim3(ceil_div_u64(P, GASM_WG / 64)), dim3(GASM_WG), 0, ps, ss.d_poscnt.as<u32>(),
+    if (P && use_graph) {
+        const u64* d_se = nullptr;
+        if (rd.n_empty) { GCHK(h2d(ctx, ss.d_seg_empty, rd.h_seg_empty.data(), (size_t)S * 8)); d_se = ss.d_seg_empty.as<u64>(); }
+        GLAUNCH(ctx, "k_score_finish", k_score_finish, dim3(ceil_div_u64(P, GASM_WG)), dim3(GASM_WG), 0, ps, ss.d_total.as<u32>(),
+                ss.d_fxsum.as<unsigned long long>(), tb.d_fix.as<long long>(), d_se, kmer, std::ldexp(1.0, -tb.fix_shift), o_bp, o_nf, o_nl,
+                o_br, o_ln, P);
+    } else if (P) {
+        GLAUNCH(ctx, "k_path_reduce", k_path_reduce, dim3(P), dim3(GASM_WG), 0, ps, ss.d_poscnt.as<u32>(),
                 ss.d_total.as<u32>(), tb.d_prob.as<double>(), kmer, o_bp, o_nf, o_nl, o_br, o_ln, P);
     }
     if (P && ss.want_freq) {
