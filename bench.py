@@ -64,14 +64,18 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import genomeassembler_dev_amd as ga
-    from genomeassembler_dev_amd import qtable, synth
+    from genomeassembler_dev_amd import parallel, qtable, synth
 
     nseg, L, rl, cov, k = WORKLOADS[args.workload]
     if args.segments_per_gpu:
         nseg = args.segments_per_gpu
     ctx = ga.Context(local_rank)
     table = qtable.load_normalised()
-    reads, seg_off, genomes = synth.make_batch(nseg, L, rl, cov, seed0=1234 + rank * nseg, planted=True)
+    # rank r owns the contiguous block of global segments parallel.shard_bounds(nseg * world, world)[r]; segment g is
+    # generated from seed 1234 + g, so the union over ranks is the same batch whatever the number of GPUs per segment count
+    seg_lo, seg_hi = parallel.shard_bounds(nseg * world, world)[rank]
+    assert seg_hi - seg_lo == nseg
+    reads, seg_off, genomes = synth.make_batch(nseg, L, rl, cov, seed0=1234 + seg_lo, planted=True)
     batch = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl, ctx=ctx)   # upload + 2-bit packing: not timed
     n_reads = int(seg_off[-1])
     n_kmers = n_reads * (rl - k + 1)
@@ -100,10 +104,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = ctx.profile_read()
     ctx.profile(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = parallel.max_over_ranks(dt, device="cuda")
 
     # ---- roofline of the dominant kernel (HIP events on the library's stream, timed steps only)
     seg, keys, mult, _w = batch.distinct()
