@@ -80,7 +80,7 @@ int gasm_get_contigs(gasm_ctx* ctx, const char* kmers, uint64_t n_kmers, int dbg
         c = new gasm_contigs();
         c->data = bs.h_contigs;
         c->off = bs.h_c_off;
-        c->words = 1;
+        c->words = bs.words;
         c->dkeys = bs.h_dk_key;
         c->dmult = bs.h_dk_cnt;
         c->rows = (u64)matrix_rows;
@@ -301,7 +301,7 @@ int gasm_batch_fetch_distinct(gasm_batch* b, const uint64_t** seg_off, const uin
     *seg_off = b->bs.h_seg_doff.data();
     *keys = b->bs.h_dk_key.data();
     *mult = b->bs.h_dk_cnt.data();
-    *words = 1;
+    *words = b->bs.words;
     return GASM_OK;
     API_GUARD_END
 }

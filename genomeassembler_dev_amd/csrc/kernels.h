@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "device_utils.h"
+#include "keyops.h"
 
 // Reads of all segments of a batch, packed 2-bit in one base stream.
 struct ReadSet {
@@ -17,7 +18,7 @@ struct ReadSet {
 
 // Sorted distinct k-mers (= distinct edges) of all segments, dense, with the per-(segment,bucket) directory.
 struct GraphView {
-    const u64* dk_key;   // D_total keys, sorted inside each segment
+    const void* dk_key;  // D_total keys (u64 or K128), sorted inside each segment
     const u32* dstart;   // n_segments * 2^bbits + 1
     const u16* fdir;     // fine directory: per bucket 2^fbits + 1 offsets (relative to the bucket) of the key bins the
                          // de-duplication kernel sorted by — the next fbits key bits below the bucket prefix
@@ -29,23 +30,25 @@ struct GraphView {
 // Lower bound of k-mer t among the distinct k-mers of segment `seg`: bucket by the first bbits bits, bin by the next
 // fbits bits (about 1.5 keys per bin), then a search inside the bin.  *bucket_hi = end of the bucket: the result is a
 // valid lower bound inside [bucket start, *bucket_hi].
-__device__ __forceinline__ u32 graph_lower_bound(const GraphView& gv, u32 seg, u64 t, u32* bucket_hi) {
+template <class K>
+__device__ __forceinline__ u32 graph_lower_bound(const GraphView& gv, u32 seg, const K& t, u32* bucket_hi) {
+    const K* dk = reinterpret_cast<const K*>(gv.dk_key);
     const u32 nb = 1u << gv.bbits;
     const int low = 2 * gv.k - gv.bbits;
-    const u32 gb = seg * nb + (gv.bbits ? (u32)(t >> low) : 0u);
+    const u32 gb = seg * nb + (gv.bbits ? kfield(t, low) : 0u);
     const u32 base = gv.dstart[gb];
     *bucket_hi = gv.dstart[gb + 1];
     const int bshift = low > gv.fbits ? low - gv.fbits : 0;
     const u32 nbin = 1u << gv.fbits;
-    const u16* f = gv.fdir + (u64)gb * (nbin + 1) + ((u32)(t >> bshift) & (nbin - 1));
+    const u16* f = gv.fdir + (u64)gb * (nbin + 1) + (kfield(t, bshift) & (nbin - 1));
     u32 lo = base + f[0];
     u32 hi = base + f[1];
     while (hi - lo > 4) {                          // only skewed bins are this long
         const u32 m = (lo + hi) >> 1;
-        if (gv.dk_key[m] < t) lo = m + 1;
+        if (kless(dk[m], t)) lo = m + 1;
         else hi = m;
     }
-    while (lo < hi && gv.dk_key[lo] < t) ++lo;     // bins usually hold one or two keys
+    while (lo < hi && kless(dk[lo], t)) ++lo;      // bins usually hold one or two keys
     return lo;
 }
 
@@ -57,35 +60,35 @@ struct PathSet {
     u32 n_segments;
 };
 
-#define GASM_KT 16          // k-mers per thread and round of k_bucket_scatter
+#define GASM_KT 16          // k-mers per thread and round of the tile kernels for 64-bit keys (8 for 128-bit keys)
 #define GASM_TBL 4096       // slots of the large LDS de-duplication table (the small one has 2048)
 #define GASM_TBL_LIMIT 2816 // distinct keys one bucket may hold (11/16 of the table) before the host re-partitions
 
 // ---- kernels_build.hip
 __global__ void k_pack_ascii(const u8* ascii, u64 nbases, u64* words, u64 nwords, u32* err);
-__global__ void k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles, u16* cube);
+template <class K> __global__ void k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles, u16* cube);
 __global__ void k_tile_scan(ReadSet rs, int bbits, u32 rt4, const u16* cube, u32* toff, u32* hist);
 template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
 __global__ void k_copy_u64(const u64* a, u64* b, u32 n);
+template <class K>
 __global__ void k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles, const u64* bstart,
-                                 const u32* toff, const u16* cube, u64* keys, int dbg);
+                                 const u32* toff, const u16* cube, K* keys, int dbg);
 #define GASM_RT_MAX 16      // rounds (read groups x offset rounds) one scatter tile may hold
-template <int TBL>
-__global__ void k_bucket_dedup(u64* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits,
-                               int dbg, unsigned long long* stamps);
-__global__ void k_bucket_gather(const u64* keys, const u32* mult, const u64* bstart, const u32* dstart, u64* dk_key,
-                                u32* dk_cnt);
-__global__ void k_node_flags(GraphView gv, u8* eflag);
-__global__ void k_edge_next(GraphView gv, const u8* eflag, u32* nxt, u64* link);
+template <class K, int TBL>
+__global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits, int dbg,
+                               unsigned long long* stamps);
+template <class K>
+__global__ void k_bucket_gather(const K* keys, const u32* mult, const u64* bstart, const u32* dstart, K* dk_key, u32* dk_cnt);
+template <class K> __global__ void k_node_flags(GraphView gv, u8* eflag);
+template <class K> __global__ void k_edge_next(GraphView gv, const u8* eflag, u32* nxt, u64* link);
 __global__ void k_link_jump(u64* link, u32 n_edges);
 __global__ void k_link_rank_seg(GraphView gv, u64* link, int max_rounds);
-__global__ void k_rank_walk(GraphView gv, const u8* eflag, const u32* nxt, u64* link, u32 n_edges, int phase);
-__global__ void k_rank_anchors(GraphView gv, const u8* eflag, u64* link, int max_rounds);
 __global__ void k_chain_len(const u8* eflag, const u32* nxt, const u64* link, u32* clen, u32 n_edges);
 __global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u32* e_cid, u64* e_coff, u32* seg_ncontig,
                               u64* seg_cbases);
 __global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* clen, const u32* seg_cstart,
                                const u64* seg_bstart, u32* e_cid, u64* e_coff, u64* c_off);
+template <class K>
 __global__ void k_contig_emit(GraphView gv, const u8* eflag, const u64* link, const u64* e_coff, u8* out, u32 n_edges);
 
 // ---- kernels_score.hip
@@ -96,6 +99,7 @@ struct SeedTable {
 };
 __global__ void k_seed_insert(PathSet ps, SeedTable st, const u64* seg_base_off, int w);
 __global__ void k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, u32* poscnt);
+template <class K>
 __global__ void k_score_reads_graph(ReadSet rs, GraphView gv, const u64* link, const u32* e_cid, PathSet ps, const long long* dfix,
                                     int kmer, u32 reads_per_wg, u32* cnt, unsigned long long* sum);
 __global__ void k_score_finish(PathSet ps, const u32* cnt, const unsigned long long* sum, const long long* dfix, const u64* seg_empty,

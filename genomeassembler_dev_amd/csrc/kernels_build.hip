@@ -15,6 +15,7 @@
 //                     lib/DeNovoAssembler.cpp:183-192: contig text, in sorted order (contigs start with distinct
 //                     k-mers, so sorting contigs = sorting their first edges)
 #include "device_utils.h"
+#include "keyops.h"
 #include "kernels.h"
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -74,26 +75,9 @@ __device__ __forceinline__ void read_span(const ReadSet& rs, u64 r, u64* p0, u32
     else { const u64 a = rs.read_off[r]; *p0 = a; *len = (u32)(rs.read_off[r + 1] - a); }
 }
 
-// Thread `lane` of the g threads that share a read takes GASM_KT consecutive k-mer starts per round:
-// offsets round*g*KT + lane*KT + [0, KT).  The 16 windows come out of three 64-bit words held in registers
-// (16 + 31 bases span at most three words), so a k-mer costs a funnel shift, not two loads.
-struct Roll3 { u64 w0, w1, w2; u32 s; };
-
-__device__ __forceinline__ Roll3 roll_load(const u64* __restrict__ w, u64 p) {
-    Roll3 r;
-    const u64 i = p >> 5;
-    r.w0 = w[i]; r.w1 = w[i + 1]; r.w2 = w[i + 2];
-    r.s = (u32)(p & 31) << 1;
-    return r;
-}
-// the 32 bases starting j bases after the load position (0 <= j < 32)
-__device__ __forceinline__ u64 roll_window(const Roll3& r, u32 j) {
-    const u32 ob = r.s + 2 * j;            // < 126
-    const bool hi = ob >= 64;
-    const u64 x = hi ? r.w1 : r.w0, y = hi ? r.w2 : r.w1;
-    const u32 o = ob & 63;
-    return (x << o) | ((y >> 1) >> (63 - o));
-}
+// Thread `lane` of the g threads that share a read takes KT consecutive k-mer starts per round: offsets
+// round*g*KT + lane*KT + [0, KT) (KT = 16 for 64-bit keys, 8 for 128-bit keys).  The windows come out of a few 64-bit
+// words held in registers (Roll<K>, keyops.h), so a k-mer costs a funnel shift, not two loads.
 
 // Count cube: for every tile, bucket, round q and wave w the number of k-mers wave w meets in round q of the tile
 // that fall into the bucket — cube[(tile * nb + b) * rt4 + q * 4 + w], 16-bit (a wave-round holds at most 1024).
@@ -101,8 +85,10 @@ __device__ __forceinline__ u64 roll_window(const Roll3& r, u32 j) {
 // concatenating sorted buckets gives a sorted segment.  A tile is `tr` groups of GASM_WG/g reads x `orr` offset rounds;
 // round q = t * orr + o handles read group t, k-mer starts o*g*KT + lane*KT + [0, KT).  k_bucket_scatter walks the tile
 // in exactly the same order, so it needs no counting of its own.
+template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles,
                                                        u16* __restrict__ cube) {
+    constexpr u32 KT = KeyTraits<K>::KT;
     extern __shared__ u32 s_h[];   // [rt][4][nb]
     const u32 nb = 1u << bbits, ipt = GASM_WG / g, rt = tr * orr, rt4 = rt * 4;
     const u32 item = threadIdx.x / g, lane = threadIdx.x % g, wv = threadIdx.x >> 6;
@@ -117,14 +103,15 @@ __global__ void __launch_bounds__(GASM_WG) k_tile_hist(ReadSet rs, int k, int bb
             read_span(rs, ti.r0 + it, &p0, &len);
             const u32 nk = len >= (u32)k ? len - k + 1 : 0;
             for (u32 o = 0; o < orr; ++o) {
-                const u32 off0 = o * g * GASM_KT + lane * GASM_KT;
+                const u32 off0 = o * g * KT + lane * KT;
                 if (off0 >= nk) break;
-                const Roll3 r = roll_load(rs.words, p0 + off0);
+                Roll<K> r;
+                r.load(rs.words, p0 + off0);
                 u32* row = s_h + ((t * orr + o) * 4 + wv) * nb;
 #pragma unroll
-                for (u32 j = 0; j < GASM_KT; ++j) {
+                for (u32 j = 0; j < KT; ++j) {
                     if (off0 + j < nk) {
-                        const u32 bkt = bbits ? (u32)(roll_window(r, j) >> (64 - bbits)) : 0u;
+                        const u32 bkt = bbits ? (u32)(r.top(j) >> (64 - bbits)) : 0u;
                         atomicAdd(&row[bkt], 1u);
                     }
                 }
@@ -139,6 +126,8 @@ __global__ void __launch_bounds__(GASM_WG) k_tile_hist(ReadSet rs, int k, int bb
         __syncthreads();
     }
 }
+template __global__ void k_tile_hist<u64>(ReadSet, int, int, u32, u32, u32, u32, u16*);
+template __global__ void k_tile_hist<K128>(ReadSet, int, int, u32, u32, u32, u32, u16*);
 
 // Per segment and bucket: tile totals from the cube, their running sum toff[tile * nb + b] (offset of the tile inside
 // its (segment,bucket) range) and the bucket total hist[seg * nb + b].  One workgroup per segment, thread = bucket.
@@ -205,24 +194,24 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
 }
 
+template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles,
                                                             const u64* __restrict__ bstart, const u32* __restrict__ toff,
-                                                            const u16* __restrict__ cube, u64* __restrict__ keys, int dbg) {
+                                                            const u16* __restrict__ cube, K* __restrict__ keys, int dbg) {
     extern __shared__ __align__(16) unsigned char s_raw[];
-    constexpr u32 WSTAGE = GASM_KT * 64;
+    constexpr u32 KT = KeyTraits<K>::KT;
+    constexpr u32 WSTAGE = KT * 64;
     const u32 rt = tr * orr, rt4 = rt * 4;
     const u32 nb = 1u << bbits, ipt = GASM_WG / g;
     const u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    u64* s_key = reinterpret_cast<u64*>(s_raw) + wv * WSTAGE;                          // 4 * WSTAGE
-    u64* s_comb = reinterpret_cast<u64*>(s_raw) + 4 * WSTAGE + wv * nb;                // 4 * nb
-    u32* s_cur = reinterpret_cast<u32*>(reinterpret_cast<u64*>(s_raw) + 4 * WSTAGE + 4 * nb) + wv * (nb + 2);   // 4 * (nb + 2): + dummy bin
+    K* s_key = reinterpret_cast<K*>(s_raw) + wv * WSTAGE;                                                   // 4 * WSTAGE
+    u64* s_comb = reinterpret_cast<u64*>(reinterpret_cast<K*>(s_raw) + 4 * WSTAGE) + wv * nb;               // 4 * nb
+    u32* s_cur = reinterpret_cast<u32*>(reinterpret_cast<u64*>(reinterpret_cast<K*>(s_raw) + 4 * WSTAGE) + 4 * nb) + wv * (nb + 2);   // 4 * (nb + 2): + dummy bin
     const u32 item = threadIdx.x / g, lane = threadIdx.x % g;
-    const int kshift = 64 - 2 * k;
     const int bshift = 2 * k - bbits;
     const bool fast = rt4 == 16 && nb <= 64;     // one bucket per lane, the bucket's 16 counts live in registers
 
-    // a workgroup takes a contiguous range of tiles: the last cache line of one tile's run in a bucket and the first of
-    // the next tile's are the same line, and only the same L2 can merge the two partial writes into one full line
+    // a workgroup takes a contiguous range of tiles (neighbouring runs of a bucket then come from the same L2)
     const u32 per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
     const u32 tile_end = min(n_tiles, (blockIdx.x + 1) * per_wg);
     for (u32 tile = blockIdx.x * per_wg; tile < tile_end; ++tile) {
@@ -249,7 +238,7 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, i
                     for (u32 e = 0; e < rt4; ++e) tot += c[e];
                     base = bstart[(u64)ti.seg * nb + b] + toff[(u64)tile * nb + b];
                 }
-                for (u32 i = tot; i < ((tot + 15u) & ~15u); ++i) keys[base + i] = GASM_EMPTY64;
+                for (u32 i = tot; i < ((tot + 15u) & ~15u); ++i) keys[base + i] = key_empty<K>();
             }
         }
         u32 run_before = 0;   // fast path: k-mers of this lane's bucket in earlier rounds (all waves)
@@ -287,9 +276,8 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, i
             }
             const u32 staged = kcar;
             wave_sync_lds();
-            // ---- rank and stage.  The sixteen ds_add_rtn of a thread are issued back to back (a position past the end of
-            // the read ranks into a dummy bin) and waited for once; a branch per k-mer would make them sixteen dependent
-            // LDS round trips.
+            // ---- rank and stage.  The ds_add_rtn of a thread are issued back to back (a position past the end of the read
+            // ranks into a dummy bin) and waited for once; a branch per k-mer would make them dependent LDS round trips.
             const u32 t = q / orr, o = q - t * orr;
             const u32 it = t * ipt + item;
             u64 p0 = 0; u32 nk = 0;
@@ -298,154 +286,216 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, i
                 read_span(rs, ti.r0 + it, &p0, &len);
                 nk = len >= (u32)k ? len - k + 1 : 0;
             }
-            const u32 off0 = o * g * GASM_KT + lane * GASM_KT;
+            const u32 off0 = o * g * KT + lane * KT;
             const bool any = off0 < nk;
-            const Roll3 rl = roll_load(rs.words, any ? p0 + off0 : 0);
-            u64 key[GASM_KT];
-            u32 idx[GASM_KT];
+            Roll<K> rl;
+            rl.load(rs.words, any ? p0 + off0 : 0);
+            K key[KT];
+            u32 idx[KT];
 #pragma unroll
-            for (u32 j = 0; j < GASM_KT; ++j) {
-                const u64 wdw = roll_window(rl, j);
-                key[j] = wdw >> kshift;
-                const u32 bkt = bbits ? (u32)(wdw >> (64 - bbits)) : 0u;
+            for (u32 j = 0; j < KT; ++j) {
+                key[j] = rl.key(j, k);
+                const u32 bkt = bbits ? (u32)(rl.top(j) >> (64 - bbits)) : 0u;
                 idx[j] = atomicAdd(&s_cur[(any && off0 + j < nk) ? bkt : nb], 1u);
             }
 #pragma unroll
-            for (u32 j = 0; j < GASM_KT; ++j)
+            for (u32 j = 0; j < KT; ++j)
                 if (any && off0 + j < nk) s_key[idx[j]] = key[j];
             wave_sync_lds();
             // ---- stream out
             if (dbg != 2) for (u32 i = ln; i < staged; i += 64) {
-                const u64 key = s_key[i];
-                const u32 bkt = bbits ? (u32)(key >> bshift) : 0u;
-                keys[s_comb[bkt] + i] = key;
+                const K kk = s_key[i];
+                const u32 bkt = bbits ? kfield(kk, bshift) : 0u;
+                keys[s_comb[bkt] + i] = kk;
             }
             wave_sync_lds();
         }
     }
 }
+template __global__ void k_bucket_scatter<u64>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, const u16*, u64*, int);
+template __global__ void k_bucket_scatter<K128>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, const u16*, K128*, int);
 
 // ================================================================================================================
-// De-duplicate one bucket: stream its keys through an LDS open-addressing table (64-bit CAS on the key, 32-bit add on
-// the multiplicity), then order the distinct keys and write them and their multiplicities back over the start of the
-// bucket's own range.  Ordering: a counting sort on the bits below the bucket prefix (TBL/4 bins; the keys of a bucket
-// share the prefix, the next bits are close to uniform) puts every key into its bin's range, bins of more than one
-// key are finished by a per-bin insertion sort; if any bin is long (skewed keys) the workgroup falls back to a
-// bitonic sort.  A bucket with more than 11/16*TBL distinct keys raises *overflow (the host re-partitions).
+// De-duplicate one bucket: stream its keys through an LDS table (count per distinct key), then order the distinct keys
+// and write them and their multiplicities back over the start of the bucket's own range.
+//
+// The table is TBL/4 sets of four slots.  A key lives in the first set with room, counted from its home set; sets fill
+// left to right.  One probe = the whole set, so unless a home set has overflowed (rare at <= 40 % load) a key is found
+// in the first probe — which matters because a wave moves at the pace of its slowest lane: with one-slot probing some
+// lane of 64 always needs a second and third round.
+//   64-bit keys : slot claimed by a 64-bit CAS on the key itself (EMPTY -> key);
+//   128-bit keys: no 128-bit CAS in LDS — the slot's count word is the lock: CAS 0 -> LOCKED, write the key, then
+//                 count = 1.  Readers compare keys only in slots whose count says "ready"; a LOCKED slot means "try
+//                 again" (never a spin inside a divergent branch: the caller's round loop simply comes back).
+// Ordering: a counting sort on the key bits below the bucket prefix (TBL/4 bins; close to uniform there) puts every key
+// into its bin's range, bins of more than one key are finished by a per-bin insertion sort; if any bin is long (skewed
+// keys) the workgroup falls back to a bitonic sort.  The bin offsets are kept as the fine directory of the graph
+// kernels.  A bucket with more than 11/16*TBL distinct keys raises *overflow (the host re-partitions).
+// launch bounds: 2048 slots of 64-bit keys fit five workgroups per CU in LDS (<= 96 registers), the other variants three.
 // ================================================================================================================
+#define GASM_SLOT_LOCKED 0xFFFFFFFFu
+
 // 16-byte LDS read that the compiler may not reuse from an earlier read (other lanes change the table meanwhile)
-__device__ __forceinline__ u64x2 lds_load128(const u64* p) {
+__device__ __forceinline__ u64x2 lds_load128(const void* p) {
     __asm__ volatile("" ::: "memory");
     return *reinterpret_cast<const u64x2*>(p);
 }
+__device__ __forceinline__ uint4 lds_load128u(const void* p) {
+    __asm__ volatile("" ::: "memory");
+    return *reinterpret_cast<const uint4*>(p);
+}
 
-// launch bounds: the 2048-slot variant fits five workgroups per CU in LDS (5 waves per SIMD: <= 96 registers), the
-// 4096-slot variant three (<= 168); without the bound the compiler used 169 and halved the residency
+// One probe of one key on set `set`: true when the key is counted, false to probe again (same set after a lost race
+// or a locked slot, next set when this one is full of other keys).
 template <int TBL>
-__global__ void __launch_bounds__(GASM_WG, TBL == 2048 ? 5 : 3) k_bucket_dedup(u64* __restrict__ keys, u32* __restrict__ mult,
-                                                          const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
-                                                          u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg,
-                                                          unsigned long long* __restrict__ stamps) {
-    constexpr int LIMIT = TBL / 16 * 11;
-    // diagnostic only (stamps == nullptr in production): per-phase wave-0 cycle totals, summed over workgroups
-    unsigned long long tph = stamps ? wall_clock64() : 0ull;
-    if (stamps && threadIdx.x == 0) {
-        // per-workgroup trace behind the 8 phase totals: start tick, end tick, hardware id
-        stamps[8 + 3 * (u64)blockIdx.x] = tph;
-        stamps[8 + 3 * (u64)blockIdx.x + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |   // HW_REG_HW_ID
-                                              ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
+__device__ __forceinline__ bool dedup_step(u64* t_key, u32* t_cnt, u32* n_distinct, u64 key, u32& set) {
+    constexpr u32 NSETS = TBL / 4;
+    const u64x2 c01 = lds_load128(&t_key[4 * set]);
+    const u64x2 c23 = lds_load128(&t_key[4 * set + 2]);
+    int slot = c01.x == key ? 0 : c01.y == key ? 1 : c23.x == key ? 2 : c23.y == key ? 3 : -1;
+    if (slot < 0) {
+        const int emp = c01.x == GASM_EMPTY64 ? 0 : c01.y == GASM_EMPTY64 ? 1 : c23.x == GASM_EMPTY64 ? 2 : c23.y == GASM_EMPTY64 ? 3 : -1;
+        if (emp < 0) { set = (set + 1) & (NSETS - 1); return false; }
+        const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&t_key[4 * set + emp]), (unsigned long long)GASM_EMPTY64,
+                                  (unsigned long long)key);
+        if (old == GASM_EMPTY64) atomicAdd(n_distinct, 1u);
+        else if (old != key) return false;       // someone else took the slot: look at the set again
+        slot = emp;
     }
-    auto phase = [&](int i) {
-        if (stamps && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&stamps[i], t - tph); tph = t; }
-    };
+    atomicAdd(&t_cnt[4 * set + slot], 1u);
+    return true;
+}
+template <int TBL>
+__device__ __forceinline__ bool dedup_step(K128* t_key, u32* t_cnt, u32* n_distinct, const K128& key, u32& set) {
+    constexpr u32 NSETS = TBL / 4;
+    const uint4 c = lds_load128u(&t_cnt[4 * set]);            // counts first: a ready count guarantees a complete key
+    const u32 cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (cc[q] == GASM_SLOT_LOCKED) return false;          // being written: may be this very key
+        if (cc[q] == 0) {
+            if (atomicCAS(&t_cnt[4 * set + q], 0u, GASM_SLOT_LOCKED) != 0u) return false;
+            t_key[4 * set + q] = key;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&t_cnt[4 * set + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            atomicAdd(n_distinct, 1u);
+            return true;
+        }
+        const u64x2 kq = lds_load128(&t_key[4 * set + q]);
+        if (kq.x == key.hi && kq.y == key.lo) { atomicAdd(&t_cnt[4 * set + q], 1u); return true; }
+    }
+    set = (set + 1) & (NSETS - 1);
+    return false;
+}
+
+template <class K, int TBL>
+__global__ void __launch_bounds__(GASM_WG, (TBL == 2048 && sizeof(K) == 8) ? 5 : 3)
+k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
+               u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg, unsigned long long* __restrict__ stamps) {
+    constexpr int LIMIT = TBL / 16 * 11;
     constexpr int BINS = TBL / 4;
     constexpr int SL = TBL / GASM_WG;
     constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
+    constexpr int LOG_SETS = LOG_TBL - 2;
+    constexpr u32 NSETS = TBL / 4;
+    constexpr bool WIDE = sizeof(K) == 16;
     static_assert(TBL == 4096 || TBL == 2048, "table size");
-    __shared__ __align__(32) u64 t_key[TBL];
-    __shared__ u32 t_cnt[TBL];
+    __shared__ __align__(32) K t_key[TBL];
+    __shared__ __align__(16) u32 t_cnt[TBL];
     __shared__ u32 s_start[BINS];
     __shared__ u32 s_cur[BINS];
     __shared__ u32 s_tmp[8];
+    // diagnostic only (stamps == nullptr in production): per-phase wave-0 tick totals, summed over workgroups
+    unsigned long long tph = stamps ? wall_clock64() : 0ull;
+    auto phase = [&](int i) {
+        if (stamps && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); atomicAdd(&stamps[i], t - tph); tph = t; }
+    };
     const u32 bucket = blockIdx.x;
     const u64 beg = bstart[bucket], end = bstart[bucket + 1];
     const u64 n = end - beg;
-    for (u32 i = threadIdx.x; i < TBL; i += GASM_WG) { t_key[i] = GASM_EMPTY64; t_cnt[i] = 0; }
+    for (u32 i = threadIdx.x; i < TBL; i += GASM_WG) { t_key[i] = key_empty<K>(); t_cnt[i] = 0; }
     for (u32 i = threadIdx.x; i < BINS; i += GASM_WG) s_start[i] = 0;
     if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }  // [4] distinct so far, [5] overflow, [6] longest bin
     __syncthreads();
     phase(0);
-    // The table is TBL/4 sets of four slots (32 bytes).  A key lives in the first set with room, counted from its
-    // home set; sets fill left to right.  One probe = the whole set (2 x ds_read_b128), so unless a home set has
-    // overflowed (rare at <= 30 % load) a key is found in the first probe — which matters because a wave moves at the
-    // pace of its slowest lane: with one-slot probing some lane of 64 always needs a second and third round.
-    constexpr u32 NSETS = TBL / 4;
-    constexpr int LOG_SETS = LOG_TBL - 2;
-    // one step for one key on set `set`: returns true when the key is counted, false to probe again (same set after a
-    // lost race, next set when this one is full of other keys)
-    auto step = [&](u64 key, u32& set) -> bool {
-        const u64x2 c01 = lds_load128(&t_key[4 * set]);
-        const u64x2 c23 = lds_load128(&t_key[4 * set + 2]);
-        int slot = c01.x == key ? 0 : c01.y == key ? 1 : c23.x == key ? 2 : c23.y == key ? 3 : -1;
-        if (slot < 0) {
-            const int emp = c01.x == GASM_EMPTY64 ? 0 : c01.y == GASM_EMPTY64 ? 1 : c23.x == GASM_EMPTY64 ? 2 : c23.y == GASM_EMPTY64 ? 3 : -1;
-            if (emp < 0) { set = (set + 1) & (NSETS - 1); return false; }
-            const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&t_key[4 * set + emp]), (unsigned long long)GASM_EMPTY64,
-                                      (unsigned long long)key);
-            if (old == GASM_EMPTY64) atomicAdd(&s_tmp[4], 1u);
-            else if (old != key) return false;       // someone else took the slot: look at the set again
-            slot = emp;
-        }
-        atomicAdd(&t_cnt[4 * set + slot], 1u);
-        return true;
-    };
-    auto insert = [&](u64 key) {
-        u32 set = hash64(key) >> (32 - LOG_SETS);
-        for (u32 probe = 0; probe < 8 * NSETS; ++probe) if (step(key, set)) return;
+    auto insert = [&](const K& key) {
+        u32 set = khash(key) >> (32 - LOG_SETS);
+        for (u32 probe = 0; probe < 8 * NSETS; ++probe) if (dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, set)) return;
         s_tmp[5] = 1;
     };
-    // 16-byte loads, four in flight per thread (the loop is latency-bound otherwise): head/tail singles, pairs between
-    const u64 a0 = (beg + 1) & ~1ull;
-    if (threadIdx.x == 0 && a0 > beg && n) { const u64 k0 = keys[beg]; if (k0 != GASM_EMPTY64) insert(k0); }
-    const u64 first = a0 < end ? a0 : end;
-    const u64 npairs = (end - first) >> 1;
-    if (threadIdx.x == 1 && ((end - first) & 1)) { const u64 k1 = keys[end - 1]; if (k1 != GASM_EMPTY64) insert(k1); }
-    const ulonglong2* kp = reinterpret_cast<const ulonglong2*>(keys + first);
-    for (u64 i = threadIdx.x; i < npairs; i += 4 * GASM_WG) {
-        if (i == threadIdx.x + 4 * GASM_WG) phase(1);   // first iteration (table fill) done
-        ulonglong2 v[4];
+    // stream: four 16-byte loads per thread in flight (the loop is latency-bound otherwise), each fully coalesced across
+    // the wave.  Bucket ranges start and end on 128-byte lines (filler keys = EMPTY are skipped).
+    constexpr int KPL = 64 / sizeof(K);          // keys per thread and iteration: 8 or 4
+    const u64 nch = n * sizeof(K) / 16;          // 16-byte chunks in the bucket
+    const uint4* src = reinterpret_cast<const uint4*>(keys + beg);
+    for (u64 c = threadIdx.x; c < nch; c += 4 * GASM_WG) {
+        if (c == (u64)threadIdx.x + 4 * GASM_WG) phase(1);   // first iteration (table fill) done
+        K kx[KPL];
+        {
+            uint4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const u64 j = i + (u64)q * GASM_WG;
-            v[q] = j < npairs ? kp[j] : make_ulonglong2(GASM_EMPTY64, GASM_EMPTY64);
+            for (int q = 0; q < 4; ++q) v[q] = c + (u64)q * GASM_WG < nch ? src[c + (u64)q * GASM_WG] : make_uint4(~0u, ~0u, ~0u, ~0u);
+            if constexpr (WIDE) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { kx[q].hi = (u64)v[q].x | ((u64)v[q].y << 32); kx[q].lo = (u64)v[q].z | ((u64)v[q].w << 32); }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { kx[2 * q] = (u64)v[q].x | ((u64)v[q].y << 32); kx[2 * q + 1] = (u64)v[q].z | ((u64)v[q].w << 32); }
+            }
         }
-        if ((dbg & 3) == 1) { u64 x = 0; for (int q = 0; q < 4; ++q) x ^= v[q].x ^ v[q].y; if (x == 0x1234567) s_tmp[6] = 1; continue; }
+        if ((dbg & 3) == 1) { u64 x = 0; for (int q = 0; q < KPL; ++q) x ^= khash(kx[q]); if (x == 0x1234567) s_tmp[6] = 1; continue; }
         if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { s_tmp[5] = 1; break; }
-        u64 kx[8];
+        if constexpr (!WIDE) {
+            // two batches of four keys: the four home sets are read together (8 x ds_read_b128 in flight), hits are
+            // counted, the few keys that are not done loop on their own
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { kx[2 * q] = v[q].x; kx[2 * q + 1] = v[q].y; }
-        // two batches of four keys: the four home sets are read together (8 x ds_read_b128 in flight), hits are counted,
-        // the few keys that are not done loop on their own
+            for (int h = 0; h < 2; ++h) {
+                u32 set[4];
+                u64x2 c01[4], c23[4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+                for (int q = 0; q < 4; ++q) {
+                    set[q] = khash(kx[4 * h + q]) >> (32 - LOG_SETS);
+                    c01[q] = lds_load128(&t_key[4 * set[q]]);
+                    c23[q] = lds_load128(&t_key[4 * set[q] + 2]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u64 key = kx[4 * h + q];
+                    if (key == GASM_EMPTY64) continue;
+                    const int slot = c01[q].x == key ? 0 : c01[q].y == key ? 1 : c23[q].x == key ? 2 : c23[q].y == key ? 3 : -1;
+                    if (slot >= 0) atomicAdd(&t_cnt[4 * set[q] + slot], 1u);
+                    else {
+                        u32 st = set[q];
+                        bool ok = false;
+                        for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
+                        if (!ok) s_tmp[5] = 1;
+                    }
+                }
+            }
+        } else {
+            // 128-bit keys: the four home sets' count words and first two slots are read together; anything not a hit in
+            // those goes through the step function
             u32 set[4];
-            u64x2 c01[4], c23[4];
+            uint4 cn[4];
+            u64x2 k0[4], k1[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                set[q] = hash64(kx[4 * h + q]) >> (32 - LOG_SETS);
-                c01[q] = lds_load128(&t_key[4 * set[q]]);
-                c23[q] = lds_load128(&t_key[4 * set[q] + 2]);
+                set[q] = khash(kx[q]) >> (32 - LOG_SETS);
+                cn[q] = lds_load128u(&t_cnt[4 * set[q]]);
+                k0[q] = lds_load128(&t_key[4 * set[q]]);
+                k1[q] = lds_load128(&t_key[4 * set[q] + 1]);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const u64 key = kx[4 * h + q];
-                if (key == GASM_EMPTY64) continue;
-                const int slot = c01[q].x == key ? 0 : c01[q].y == key ? 1 : c23[q].x == key ? 2 : c23[q].y == key ? 3 : -1;
-                if (slot >= 0) atomicAdd(&t_cnt[4 * set[q] + slot], 1u);
+                const K128 key = kx[q];
+                if (kis_empty(key)) continue;
+                const bool r0 = cn[q].x != 0 && cn[q].x != GASM_SLOT_LOCKED, r1 = cn[q].y != 0 && cn[q].y != GASM_SLOT_LOCKED;
+                if (r0 && k0[q].x == key.hi && k0[q].y == key.lo) atomicAdd(&t_cnt[4 * set[q]], 1u);
+                else if (r0 && r1 && k1[q].x == key.hi && k1[q].y == key.lo) atomicAdd(&t_cnt[4 * set[q] + 1], 1u);
                 else {
                     u32 st = set[q];
                     bool ok = false;
-                    for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = step(key, st);
+                    for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
                     if (!ok) s_tmp[5] = 1;
                 }
             }
@@ -462,13 +512,14 @@ __global__ void __launch_bounds__(GASM_WG, TBL == 2048 ? 5 : 3) k_bucket_dedup(u
     if ((dbg & 3) == 1 || (dbg & 3) == 2) { if (threadIdx.x == 0) bucket_d[bucket] = d; return; }
     // ---- every thread pulls its slots (stride 256: conflict-free) into registers and bins them
     const int bshift = low_bits > (LOG_TBL - 2) ? low_bits - (LOG_TBL - 2) : 0;
-    u64 rk[SL];
+    K rk[SL];
     u32 rc[SL];
 #pragma unroll
     for (int q = 0; q < SL; ++q) {
         rk[q] = t_key[q * GASM_WG + threadIdx.x];
         rc[q] = t_cnt[q * GASM_WG + threadIdx.x];
-        if (rk[q] != GASM_EMPTY64) atomicAdd(&s_start[(u32)(rk[q] >> bshift) & (BINS - 1)], 1u);
+        if (WIDE && rc[q] == 0) rk[q] = key_empty<K>();      // 128-bit tables mark free slots by the count
+        if (!kis_empty(rk[q])) atomicAdd(&s_start[kfield(rk[q], bshift) & (BINS - 1)], 1u);
     }
     __syncthreads();   // all table reads and all bin counts are done
     {
@@ -491,8 +542,8 @@ __global__ void __launch_bounds__(GASM_WG, TBL == 2048 ? 5 : 3) k_bucket_dedup(u
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < SL; ++q) {
-        if (rk[q] != GASM_EMPTY64) {
-            const u32 pos = atomicAdd(&s_cur[(u32)(rk[q] >> bshift) & (BINS - 1)], 1u);
+        if (!kis_empty(rk[q])) {
+            const u32 pos = atomicAdd(&s_cur[kfield(rk[q], bshift) & (BINS - 1)], 1u);
             t_key[pos] = rk[q];
             t_cnt[pos] = rc[q];
         }
@@ -504,10 +555,10 @@ __global__ void __launch_bounds__(GASM_WG, TBL == 2048 ? 5 : 3) k_bucket_dedup(u
         for (u32 b = threadIdx.x; b < (u32)BINS; b += GASM_WG) {
             const u32 lo = s_start[b], hi = s_cur[b];
             for (u32 i = lo + 1; i < hi; ++i) {
-                const u64 kx = t_key[i];
+                const K kx = t_key[i];
                 const u32 cx = t_cnt[i];
                 u32 j = i;
-                while (j > lo && t_key[j - 1] > kx) { t_key[j] = t_key[j - 1]; t_cnt[j] = t_cnt[j - 1]; --j; }
+                while (j > lo && kless(kx, t_key[j - 1])) { t_key[j] = t_key[j - 1]; t_cnt[j] = t_cnt[j - 1]; --j; }
                 t_key[j] = kx;
                 t_cnt[j] = cx;
             }
@@ -517,16 +568,16 @@ __global__ void __launch_bounds__(GASM_WG, TBL == 2048 ? 5 : 3) k_bucket_dedup(u
         // skewed keys: bitonic sort of the compacted entries
         u32 p2 = 2;
         while (p2 < d) p2 <<= 1;
-        for (u32 i = d + threadIdx.x; i < p2; i += GASM_WG) { t_key[i] = GASM_EMPTY64; t_cnt[i] = 0; }
+        for (u32 i = d + threadIdx.x; i < p2; i += GASM_WG) { t_key[i] = key_empty<K>(); t_cnt[i] = 0; }
         __syncthreads();
         for (u32 kk = 2; kk <= p2; kk <<= 1) {
             for (u32 j = kk >> 1; j > 0; j >>= 1) {
                 for (u32 t = threadIdx.x; t < (p2 >> 1); t += GASM_WG) {
                     const u32 lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                     const u32 hi = lo | j;
-                    const u64 a = t_key[lo], b = t_key[hi];
+                    const K a = t_key[lo], b = t_key[hi];
                     const bool up = (lo & kk) == 0;
-                    if ((a > b) == up) {
+                    if (kless(b, a) == up && !keq(a, b)) {
                         t_key[lo] = b; t_key[hi] = a;
                         const u32 ca = t_cnt[lo], cb = t_cnt[hi];
                         t_cnt[lo] = cb; t_cnt[hi] = ca;
@@ -542,74 +593,87 @@ __global__ void __launch_bounds__(GASM_WG, TBL == 2048 ? 5 : 3) k_bucket_dedup(u
     phase(5);
     if (stamps && threadIdx.x == 0) stamps[8 + 3 * (u64)blockIdx.x + 1] = wall_clock64();
 }
-template __global__ void k_bucket_dedup<4096>(u64*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
-template __global__ void k_bucket_dedup<2048>(u64*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
+template __global__ void k_bucket_dedup<u64, 4096>(u64*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
+template __global__ void k_bucket_dedup<u64, 2048>(u64*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
+template __global__ void k_bucket_dedup<K128, 2048>(K128*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
 
 // Gather the per-bucket distinct runs into the dense per-segment arrays.
-__global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const u64* __restrict__ keys, const u32* __restrict__ mult,
+template <class K>
+__global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const K* __restrict__ keys, const u32* __restrict__ mult,
                                                            const u64* __restrict__ bstart, const u32* __restrict__ dstart,
-                                                           u64* __restrict__ dk_key, u32* __restrict__ dk_cnt) {
+                                                           K* __restrict__ dk_key, u32* __restrict__ dk_cnt) {
     const u32 bucket = blockIdx.x;
     const u64 src = bstart[bucket];
     const u32 dst = dstart[bucket], d = dstart[bucket + 1] - dst;
     for (u32 i = threadIdx.x; i < d; i += GASM_WG) { dk_key[dst + i] = keys[src + i]; dk_cnt[dst + i] = mult[src + i]; }
 }
+template __global__ void k_bucket_gather<u64>(const u64*, const u32*, const u64*, const u32*, u64*, u32*);
+template __global__ void k_bucket_gather<K128>(const K128*, const u32*, const u64*, const u32*, K128*, u32*);
 
 // ================================================================================================================
 // Graph over the sorted distinct k-mers (= distinct edges) of each segment.  Edge i: key = x·M·y, source node
 // u = key>>2 (x·M), target node v = key & mask (M·y).  blockIdx.y = segment.
 // ================================================================================================================
-__device__ __forceinline__ bool kmer_exists(const GraphView& gv, u32 seg, u64 t) {
+template <class K>
+__device__ __forceinline__ bool kmer_exists(const GraphView& gv, u32 seg, const K& t) {
     u32 hi;
-    const u32 j = graph_lower_bound(gv, seg, t, &hi);
-    return j < hi && gv.dk_key[j] == t;
+    const u32 j = graph_lower_bound<K>(gv, seg, t, &hi);
+    return j < hi && keq(reinterpret_cast<const K*>(gv.dk_key)[j], t);
 }
 
 // flag bit0: the edge's source node is a branching node (in != 1 or out != 1); it has out-edges by construction.
+template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u8* __restrict__ eflag) {
+    const K* dk = reinterpret_cast<const K*>(gv.dk_key);
     const u32 seg = blockIdx.y;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
     const u32 i = lo + blockIdx.x * GASM_WG + threadIdx.x;
     if (i >= hi) return;
-    const u64 key = gv.dk_key[i];
-    const u64 u = key >> 2;
+    const K key = dk[i];
+    const K u = kshr(key, 2);
     // out-degree of u: the run of keys sharing key>>2 is contiguous in the sorted list
     u32 outd = 1;
-    for (u32 j = i; j > lo && (gv.dk_key[j - 1] >> 2) == u; --j) ++outd;
-    for (u32 j = i + 1; j < hi && (gv.dk_key[j] >> 2) == u; ++j) ++outd;
+    for (u32 j = i; j > lo && keq(kshr(dk[j - 1], 2), u); --j) ++outd;
+    for (u32 j = i + 1; j < hi && keq(kshr(dk[j], 2), u); ++j) ++outd;
     // in-degree of u: distinct k-mers x·u
     u32 ind = 0;
     const int sh = 2 * (gv.k - 1);
 #pragma unroll
-    for (u64 x = 0; x < 4; ++x) ind += kmer_exists(gv, seg, (x << sh) | u);
+    for (u64 x = 0; x < 4; ++x) ind += kmer_exists<K>(gv, seg, kor(kshl(key_from_u64<K>(x), sh), u));
     eflag[i] = (ind != 1 || outd != 1) ? 1 : 0;
 }
+template __global__ void k_node_flags<u64>(GraphView, u8*);
+template __global__ void k_node_flags<K128>(GraphView, u8*);
 
 // Successor edge of every edge (GASM_NONE32 when the walk stops at its target), and the initial ancestor links:
 // link = ancestor << 32 | done << 31 | distance, done = "the ancestor is the head of the chain".  Heads are their own
 // ancestor at distance 0.  The done bit travels with the link, so pointer doubling needs one gather per round.
+template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, const u8* __restrict__ eflag, u32* __restrict__ nxt,
                                                        u64* __restrict__ link) {
+    const K* dk = reinterpret_cast<const K*>(gv.dk_key);
     const u32 seg = blockIdx.y;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
     const u32 i = lo + blockIdx.x * GASM_WG + threadIdx.x;
     if (i >= hi) return;
-    const u64 key = gv.dk_key[i];
+    const K key = dk[i];
     const int sh = 2 * (gv.k - 1);
-    const u64 v = sh ? (key & ((1ull << sh) - 1)) : 0ull;
-    const u64 t = v << 2;  // smallest k-mer with prefix v
+    const K v = klowbits(key, sh);
+    const K t = kshl(v, 2);  // smallest k-mer with prefix v
     // the run of v may continue into the next bucket only if bbits > 2(k-1), which the host never chooses
     u32 bhi;
-    const u32 j = graph_lower_bound(gv, seg, t, &bhi);
+    const u32 j = graph_lower_bound<K>(gv, seg, t, &bhi);
     u32 n = GASM_NONE32;
-    if (j < bhi && (gv.dk_key[j] >> 2) == v && !(eflag[j] & 1)) n = j;  // v has out-edges and is not branching
+    if (j < bhi && keq(kshr(dk[j], 2), v) && !(eflag[j] & 1)) n = j;  // v has out-edges and is not branching
     nxt[i] = n;
     const u64 me_head = (eflag[i] & 1) ? GASM_LINK_DONE : 0ull;
     if (n != GASM_NONE32) link[n] = ((u64)i << 32) | me_head | 1ull;
     if (me_head) link[i] = ((u64)i << 32) | GASM_LINK_DONE;
 }
+template __global__ void k_edge_next<u64>(GraphView, const u8*, u32*, u64*);
+template __global__ void k_edge_next<K128>(GraphView, const u8*, u32*, u64*);
 
 // One round of pointer doubling towards the head of the chain.  In place and asynchronous: a link is always a
 // consistent (ancestor, done, distance) triple because it is read and written as one 64-bit word.
@@ -665,100 +729,6 @@ __global__ void __launch_bounds__(1024) k_link_rank_seg(GraphView gv, u64* __res
                 else { nl = ((u64)a2 << 32) | (la[q] & GASM_LINK_DONE) | d; any = any || !(la[q] & GASM_LINK_DONE); }
                 __hip_atomic_store(&link[i], nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-        }
-        if (any) s_active = 1;
-        __syncthreads();
-        const bool go = s_active != 0;
-        __syncthreads();
-        if (!go) break;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// List ranking by a ruling set (work O(D) instead of O(D log D)).  Anchors = chain heads + a pseudo-random eighth of
-// the edges.
-//   k_rank_walk phase 1: every anchor walks forward to the next anchor and leaves (itself, steps) there as that
-//                        anchor's ancestor link — gaps are ~8 edges, < 100 with overwhelming probability;
-//   k_rank_anchors     : pointer doubling over the anchors only (one workgroup per segment, the anchor list in LDS);
-//   k_rank_walk phase 3: every ranked anchor walks its gap again and writes (head, done, distance) on the edges in it.
-// Members of isolated cycles never get a done link, exactly as with plain pointer doubling.
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool is_anchor(u32 i, u8 flag) { return (flag & 1) || ((i * 0x9E3779B1u) >> 29) == 0; }
-
-__global__ void __launch_bounds__(GASM_WG) k_rank_walk(GraphView gv, const u8* __restrict__ eflag, const u32* __restrict__ nxt,
-                                                       u64* __restrict__ link, u32 n_edges, int phase) {
-    const u32 i = blockIdx.x * GASM_WG + threadIdx.x;
-    if (i >= n_edges) return;
-    const u8 f = eflag[i];
-    if (!is_anchor(i, f)) return;
-    (void)gv;
-    if (phase == 1) {
-        u32 cur = i;
-        for (u32 steps = 1; steps <= n_edges; ++steps) {
-            const u32 n = nxt[cur];
-            if (n == GASM_NONE32) break;
-            if (is_anchor(n, eflag[n])) {     // n is never a head: heads are nobody's successor
-                link[n] = ((u64)i << 32) | ((f & 1) ? GASM_LINK_DONE : 0ull) | steps;
-                break;
-            }
-            cur = n;
-        }
-    } else {
-        const u64 l = link[i];
-        if ((u32)(l >> 32) == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;   // anchor on an isolated cycle
-        const u64 head = l & 0xFFFFFFFF00000000ull;
-        u32 d = (u32)l & 0x7FFFFFFFu;
-        u32 cur = i;
-        for (u32 steps = 1; steps <= n_edges; ++steps) {
-            const u32 n = nxt[cur];
-            if (n == GASM_NONE32 || is_anchor(n, eflag[n])) break;
-            ++d;
-            link[n] = head | GASM_LINK_DONE | d;
-            cur = n;
-        }
-    }
-}
-
-#define GASM_ANCHOR_CAP 12288
-__global__ void __launch_bounds__(1024) k_rank_anchors(GraphView gv, const u8* __restrict__ eflag, u64* __restrict__ link, int max_rounds) {
-    __shared__ u32 s_list[GASM_ANCHOR_CAP];
-    __shared__ u32 s_n, s_active;
-    const u32 seg = blockIdx.x;
-    const u32 nb = 1u << gv.bbits;
-    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 n = hi - lo;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    // unranked anchors of this segment (heads are ranked already: their own ancestor, done)
-    for (u32 i = lo + threadIdx.x; i < hi; i += 1024) {
-        const u8 f = eflag[i];
-        if (!(f & 1) && is_anchor(i, f)) {
-            const u32 p = atomicAdd(&s_n, 1u);
-            if (p < GASM_ANCHOR_CAP) s_list[p] = i;
-        }
-    }
-    __syncthreads();
-    const u32 na = s_n;
-    const bool listed = na <= GASM_ANCHOR_CAP;     // else walk the whole segment every round
-    const u32 count = listed ? na : n;
-    for (int r = 0; r < max_rounds; ++r) {
-        if (threadIdx.x == 0) s_active = 0;
-        __syncthreads();
-        bool any = false;
-        for (u32 e = threadIdx.x; e < count; e += 1024) {
-            u32 i;
-            if (listed) i = s_list[e];
-            else { i = lo + e; const u8 f = eflag[i]; if ((f & 1) || !is_anchor(i, f)) continue; }
-            const u64 l = __hip_atomic_load(&link[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const u32 a = (u32)(l >> 32);
-            if (a == GASM_NONE32 || (l & GASM_LINK_DONE)) continue;
-            const u64 la = __hip_atomic_load(&link[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const u32 a2 = (u32)(la >> 32);
-            const u32 d = ((u32)l & 0x7FFFFFFFu) + ((u32)la & 0x7FFFFFFFu);
-            u64 nl;
-            if (a2 == GASM_NONE32 || d > n) nl = ~0ull;            // on an isolated cycle
-            else { nl = ((u64)a2 << 32) | (la & GASM_LINK_DONE) | d; any = any || !(la & GASM_LINK_DONE); }
-            __hip_atomic_store(&link[i], nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (any) s_active = 1;
         __syncthreads();
@@ -825,6 +795,7 @@ __global__ void __launch_bounds__(GASM_WG) k_contig_place(GraphView gv, const u8
 }
 
 // Every edge on a chain writes its last base at head offset + (k-1) + distance; the head also writes its node.
+template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_contig_emit(GraphView gv, const u8* __restrict__ eflag, const u64* __restrict__ link,
                                                          const u64* __restrict__ e_coff, u8* __restrict__ out, u32 n_edges) {
     const u32 i = blockIdx.x * GASM_WG + threadIdx.x;
@@ -833,11 +804,13 @@ __global__ void __launch_bounds__(GASM_WG) k_contig_emit(GraphView gv, const u8*
     const u32 a = (u32)(l >> 32);
     if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;
     (void)eflag;
-    const u64 key = gv.dk_key[i];
+    const K key = reinterpret_cast<const K*>(gv.dk_key)[i];
     const u64 off = e_coff[a];
     const int k = gv.k;
-    out[off + (k - 1) + ((u32)l & 0x7FFFFFFFu)] = "ACGT"[key & 3];
+    out[off + (k - 1) + ((u32)l & 0x7FFFFFFFu)] = "ACGT"[klow2(key)];
     if (a == i) {
-        for (int j = 0; j < k - 1; ++j) out[off + j] = "ACGT"[(key >> (2 * (k - 1 - j))) & 3];
+        for (int j = 0; j < k - 1; ++j) out[off + j] = "ACGT"[klow2(kshr(key, 2 * (k - 1 - j)))];
     }
 }
+template __global__ void k_contig_emit<u64>(GraphView, const u8*, const u64*, const u64*, u8*, u32);
+template __global__ void k_contig_emit<K128>(GraphView, const u8*, const u64*, const u64*, u8*, u32);

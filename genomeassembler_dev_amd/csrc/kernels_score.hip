@@ -104,20 +104,22 @@ __global__ void __launch_bounds__(GASM_WG) k_read_match(ReadSet rs, PathSet ps, 
 // contig, once, so this is the only place the read can occur: compare the rest of the read there
 // (lib/DeNovoAssembler.cpp:360).
 // Returns the global base position of the hit, or ~0 when the read matches no contig.
+template <class K>
 __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& gv, const u64* __restrict__ link,
-                                           const u32* __restrict__ e_cid, const PathSet& ps, u32 seg, u64 r) {
+                                           const u32* __restrict__ e_cid, const PathSet& ps, u32 seg, u64 r, u32* path) {
     u64 p0; u32 len;
     if (rs.fixed_len) { p0 = r * rs.fixed_len; len = rs.fixed_len; }
     else { p0 = rs.read_off[r]; len = (u32)(rs.read_off[r + 1] - p0); }
     if (len < (u32)gv.k) return ~0ull;
-    const u64 key = kmer_at(rs.words, p0, gv.k);
+    const K key = kmer_key_at<K>(rs.words, p0, gv.k);
     u32 hi;
-    const u32 e = graph_lower_bound(gv, seg, key, &hi);
-    if (e >= hi || gv.dk_key[e] != key) return ~0ull;
+    const u32 e = graph_lower_bound<K>(gv, seg, key, &hi);
+    if (e >= hi || !keq(reinterpret_cast<const K*>(gv.dk_key)[e], key)) return ~0ull;
     const u64 l = link[e];
     const u32 a = (u32)(l >> 32);
     if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return ~0ull;   // on an isolated cycle: part of no contig
     const u32 c = e_cid[a];
+    *path = c;
     const u64 g = ps.p_off[c] + ((u32)l & 0x7FFFFFFFu);
     if (g + len > ps.p_off[c + 1]) return ~0ull;
     bool same = true;
@@ -137,6 +139,7 @@ __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& g
 // flushes the non-zero ones with global atomics at the end; segments with more paths than fit go to global atomics
 // directly.  blockIdx.y = segment, blockIdx.x = slice of the segment's reads.
 #define GASM_SCORE_PATH_CAP 6144
+template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, GraphView gv, const u64* __restrict__ link,
                                                                const u32* __restrict__ e_cid, PathSet ps,
                                                                const long long* __restrict__ dfix, int kmer, u32 reads_per_wg,
@@ -153,10 +156,9 @@ __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, Graph
     if (in_lds) for (u32 i = threadIdx.x; i < np; i += GASM_WG) { s_sum[i] = 0; s_cnt[i] = 0; }
     __syncthreads();
     for (u64 r = r0 + threadIdx.x; r < r1; r += GASM_WG) {
-        const u64 g = graph_match(rs, gv, link, e_cid, ps, seg, r);
+        u32 c = 0;
+        const u64 g = graph_match<K>(rs, gv, link, e_cid, ps, seg, r, &c);
         if (g == ~0ull) continue;
-        // path of the hit: the contig list of the segment is short; upper_seg is a binary search over its offsets
-        const u32 c = pfirst + upper_seg<u64>(ps.p_off + pfirst, np, g);
         const u64 pb = ps.p_off[c];
         const u32 plen = (u32)(ps.p_off[c + 1] - pb);
         u32 idx;
@@ -171,6 +173,11 @@ __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, Graph
         if (c) { atomicAdd(&cnt[pfirst + i], c); atomicAdd(&sum[pfirst + i], s_sum[i]); }
     }
 }
+
+template __global__ void k_score_reads_graph<u64>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32*,
+                                                  unsigned long long*);
+template __global__ void k_score_reads_graph<K128>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32*,
+                                                   unsigned long long*);
 
 // Fixed-point sums -> the reference's per-path numbers.  `seg_empty`: empty reads of the path's segment, each a hit at
 // position 0 of every path (std::string::find("") == 0).

@@ -1,0 +1,116 @@
+// keyops.h — k-mer keys as integers: u64 for k <= 31, K128 (two words, hi:lo) for 32 <= k <= 63.
+// A key holds the k bases right-aligned in 2k bits, first base most significant, so integer order = string order.
+// The kernels are templates over the key type and only use the overloaded operations below.
+#pragma once
+#include "device_utils.h"
+
+struct __attribute__((aligned(16))) K128 {
+    u64 hi, lo;
+};
+
+// ---- construction / constants
+template <class K> __device__ __forceinline__ K key_empty();
+template <> __device__ __forceinline__ u64 key_empty<u64>() { return GASM_EMPTY64; }
+template <> __device__ __forceinline__ K128 key_empty<K128>() { return K128{GASM_EMPTY64, GASM_EMPTY64}; }
+template <class K> __device__ __forceinline__ K key_from_u64(u64 v);
+template <> __device__ __forceinline__ u64 key_from_u64<u64>(u64 v) { return v; }
+template <> __device__ __forceinline__ K128 key_from_u64<K128>(u64 v) { return K128{0, v}; }
+
+// ---- comparisons
+__device__ __forceinline__ bool keq(u64 a, u64 b) { return a == b; }
+__device__ __forceinline__ bool keq(const K128& a, const K128& b) { return a.hi == b.hi && a.lo == b.lo; }
+__device__ __forceinline__ bool kless(u64 a, u64 b) { return a < b; }
+__device__ __forceinline__ bool kless(const K128& a, const K128& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
+__device__ __forceinline__ bool kis_empty(u64 a) { return a == GASM_EMPTY64; }
+__device__ __forceinline__ bool kis_empty(const K128& a) { return (a.hi & a.lo) == GASM_EMPTY64; }
+
+// ---- shifts (0 <= s < width) and bit operations
+__device__ __forceinline__ u64 kshr(u64 a, int s) { return a >> s; }
+__device__ __forceinline__ K128 kshr(const K128& a, int s) {
+    if (s == 0) return a;
+    if (s >= 64) return K128{0, a.hi >> (s - 64)};
+    return K128{a.hi >> s, (a.lo >> s) | (a.hi << (64 - s))};
+}
+__device__ __forceinline__ u64 kshl(u64 a, int s) { return a << s; }
+__device__ __forceinline__ K128 kshl(const K128& a, int s) {
+    if (s == 0) return a;
+    if (s >= 64) return K128{a.lo << (s - 64), 0};
+    return K128{(a.hi << s) | (a.lo >> (64 - s)), a.lo << s};
+}
+__device__ __forceinline__ u64 kor(u64 a, u64 b) { return a | b; }
+__device__ __forceinline__ K128 kor(const K128& a, const K128& b) { return K128{a.hi | b.hi, a.lo | b.lo}; }
+// the low `bits` bits (0 <= bits <= width)
+__device__ __forceinline__ u64 klowbits(u64 a, int bits) { return bits >= 64 ? a : (a & ((1ull << bits) - 1)); }
+__device__ __forceinline__ K128 klowbits(const K128& a, int bits) {
+    if (bits >= 128) return a;
+    if (bits >= 64) return K128{bits == 64 ? 0 : (a.hi & ((1ull << (bits - 64)) - 1)), a.lo};
+    return K128{0, a.lo & ((1ull << bits) - 1)};
+}
+// low 32 bits of (a >> s)
+__device__ __forceinline__ u32 kfield(u64 a, int s) { return (u32)(a >> s); }
+__device__ __forceinline__ u32 kfield(const K128& a, int s) { return (u32)kshr(a, s).lo; }
+__device__ __forceinline__ u32 klow2(u64 a) { return (u32)a & 3u; }
+__device__ __forceinline__ u32 klow2(const K128& a) { return (u32)a.lo & 3u; }
+
+__device__ __forceinline__ u32 khash(u64 a) { return hash64(a); }
+__device__ __forceinline__ u32 khash(const K128& a) { return hash64(a.lo ^ (a.hi * 0xD6E8FEB86659FD93ull)); }
+
+// ---- windows of a packed base stream
+// the k bases starting at base p as a key (k <= 31 for u64, k <= 63 for K128)
+template <class K> __device__ __forceinline__ K kmer_key_at(const u64* __restrict__ w, u64 p, int k);
+template <> __device__ __forceinline__ u64 kmer_key_at<u64>(const u64* __restrict__ w, u64 p, int k) { return window32(w, p) >> (64 - 2 * k); }
+template <> __device__ __forceinline__ K128 kmer_key_at<K128>(const u64* __restrict__ w, u64 p, int k) {
+    const K128 win{window32(w, p), window32(w, p + 32)};     // 64 bases from p
+    return kshr(win, 128 - 2 * k);
+}
+
+// Rolling source: KT consecutive k-mer starts out of a few words held in registers (3 words cover 16 + 31 bases,
+// 4 words cover 8 + 63 + 31 bases).
+template <class K> struct Roll;
+template <> struct Roll<u64> {
+    u64 w0, w1, w2;
+    u32 s;
+    __device__ __forceinline__ void load(const u64* __restrict__ w, u64 p) {
+        const u64 i = p >> 5;
+        w0 = w[i]; w1 = w[i + 1]; w2 = w[i + 2];
+        s = (u32)(p & 31) << 1;
+    }
+    // the 32 bases starting j bases after the load position (0 <= j < 32): also the top of every k-mer there
+    __device__ __forceinline__ u64 top(u32 j) const {
+        const u32 ob = s + 2 * j;            // < 126
+        const bool hi = ob >= 64;
+        const u64 x = hi ? w1 : w0, y = hi ? w2 : w1;
+        const u32 o = ob & 63;
+        return (x << o) | ((y >> 1) >> (63 - o));
+    }
+    __device__ __forceinline__ u64 key(u32 j, int k) const { return top(j) >> (64 - 2 * k); }
+};
+template <> struct Roll<K128> {
+    u64 w0, w1, w2, w3;
+    u32 s;
+    __device__ __forceinline__ void load(const u64* __restrict__ w, u64 p) {
+        const u64 i = p >> 5;
+        w0 = w[i]; w1 = w[i + 1]; w2 = w[i + 2]; w3 = w[i + 3];
+        s = (u32)(p & 31) << 1;
+    }
+    __device__ __forceinline__ u64 word(u32 ob, const u64& a, const u64& b) const { return ob ? ((a << ob) | (b >> (64 - ob))) : a; }
+    // j < 32 - ... : the window needs bases [j, j + 64): with s <= 62 and j <= 15 that is inside the four words
+    __device__ __forceinline__ u64 top(u32 j) const {
+        const u32 ob = s + 2 * j;            // < 126 for j < 32
+        const bool hi = ob >= 64;
+        const u32 o = ob & 63;
+        return hi ? word(o, w1, w2) : word(o, w0, w1);
+    }
+    __device__ __forceinline__ K128 key(u32 j, int k) const {
+        const u32 ob = s + 2 * j;
+        const bool hi = ob >= 64;
+        const u32 o = ob & 63;
+        const K128 win{hi ? word(o, w1, w2) : word(o, w0, w1), hi ? word(o, w2, w3) : word(o, w1, w2)};
+        return kshr(win, 128 - 2 * k);
+    }
+};
+
+// words per key and k-mers per thread and round of the tile kernels (LDS staging is 8 KB per wave either way)
+template <class K> struct KeyTraits;
+template <> struct KeyTraits<u64> { static constexpr int WORDS = 1; static constexpr int KT = 16; };
+template <> struct KeyTraits<K128> { static constexpr int WORDS = 2; static constexpr int KT = 8; };

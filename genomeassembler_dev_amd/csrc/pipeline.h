@@ -48,7 +48,7 @@ struct DevPaths {
 };
 
 struct BuildState {
-    int k = 0, bbits = 0, fbits = 9;
+    int k = 0, bbits = 0, fbits = 9, words = 1;
     u64 n_kmers = 0;
     u32 d_total = 0, n_contigs = 0;
     u64 contig_bases = 0;

@@ -44,8 +44,8 @@ static int d2h_sync(gasm_ctx* ctx, void* dst, const void* src, size_t bytes) {
 
 static int pack_ascii(gasm_ctx* ctx, const u8* d_ascii, u64 nbases, DBuf& words, u32* d_err) {
     const u64 nw = (nbases + 31) / 32;
-    GCHK(words.ensure((nw + 2) * 8));
-    HIPCHK(hipMemsetAsync((u64*)words.p + nw, 0, 16, ctx->stream));
+    GCHK(words.ensure((nw + 4) * 8));     // four zero padding words: a 128-bit rolling window reads up to three words ahead
+    HIPCHK(hipMemsetAsync((u64*)words.p + nw, 0, 32, ctx->stream));
     if (nw) GLAUNCH(ctx, "k_pack_ascii", k_pack_ascii, dim3(ceil_div_u64(nw, GASM_WG)), dim3(GASM_WG), 0, d_ascii, nbases,
                     words.as<u64>(), nw, d_err);
     return GASM_OK;
@@ -208,7 +208,11 @@ void ScoreState::release() {
 // build
 // ---------------------------------------------------------------------------------------------------------------
 int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs) {
-    if (k < 2 || k > 31) { gasm_set_error("k = %d not supported by this build (2..31)", k); return GASM_ERR_INVALID; }
+    if (k < 2 || k > GASM_MAX_K) { gasm_set_error("k = %d not supported (2..%d)", k, GASM_MAX_K); return GASM_ERR_INVALID; }
+    const int W = k <= 31 ? 1 : 2;            // 64-bit keys up to k = 31, 128-bit keys (K128) up to k = 63
+    const size_t KB = 8 * (size_t)W;
+    const u32 KT = W == 1 ? 16u : 8u;         // k-mers per thread and round of the tile kernels (KeyTraits<K>::KT)
+    bs.words = W;
     HIPCHK(hipSetDevice(ctx->device));
     const u32 S = rd.n_segments;
     bs.fetched_distinct = bs.fetched_contigs = false;
@@ -232,12 +236,12 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     }
     bs.n_kmers = N;
     const u32 nk_max = rd.max_len >= (u32)k ? rd.max_len - k + 1 : 0;
-    u32 g = next_pow2_u32((nk_max + GASM_KT - 1) / GASM_KT);
+    u32 g = next_pow2_u32((nk_max + KT - 1) / KT);
     g = std::max(1u, std::min(64u, g));
     const u32 ipt = GASM_WG / g;
     // a scatter tile = tr read groups x orr offset rounds (orr > 1 only for reads longer than g*KT k-mers)
-    const u32 orr = std::max(1u, (nk_max + g * GASM_KT - 1) / (g * GASM_KT));
-    if (orr > GASM_RT_MAX) { gasm_set_error("reads longer than %u bases are not supported", 64u * GASM_KT * GASM_RT_MAX); return GASM_ERR_CAPACITY; }
+    const u32 orr = std::max(1u, (nk_max + g * KT - 1) / (g * KT));
+    if (orr > GASM_RT_MAX) { gasm_set_error("reads longer than %u bases are not supported", 64u * KT * GASM_RT_MAX); return GASM_ERR_CAPACITY; }
     const u32 tr = orr == 1 ? 4u : 1u;
     GCHK(rd.set_tiles(ctx, ipt * tr));
     // bucket bits: aim at <= ~900 distinct k-mers per bucket (2048-slot LDS table in 4-slot sets, limit 1408)
@@ -255,13 +259,16 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
         small_tbl = (dest >> bbits) <= 900;   // else the 4096-slot table (fewer workgroups per CU)
         if (getenv("GASM_DEDUP_TBL")) small_tbl = atoi(getenv("GASM_DEDUP_TBL")) == 2048;
+        if (W == 2) small_tbl = true;         // 128-bit keys: 2048-slot tables only
     }
     const int dbg_s = getenv("GASM_DBG_SCATTER") ? atoi(getenv("GASM_DBG_SCATTER")) : 0;   // tuning ablations (wrong results!)
     const int dbg_d = getenv("GASM_DBG_DEDUP") ? atoi(getenv("GASM_DBG_DEDUP")) : 0;
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_attr_set = true;
     }
     if (N == 0) {
@@ -285,7 +292,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 4));
         {
             const u64 n_alloc = std::min<u64>(n_pad_max, N + 16ull * rd.n_tiles * nb);
-            GCHK(bs.d_keys.ensure(n_alloc * 8));
+            GCHK(bs.d_keys.ensure(n_alloc * KB));
             GCHK(bs.d_mult.ensure(n_alloc * 4));
         }
         GCHK(bs.d_cube.ensure((size_t)rd.n_tiles * nb * tr * orr * 4 * 2 + 64));
@@ -296,22 +303,32 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 64, ctx->stream));
         const u32 rt = tr * orr;
         if ((size_t)rt * 4 * nb * 4 > 160 * 1024) { gasm_set_error("count cube does not fit LDS"); return GASM_ERR_CAPACITY; }
-        GLAUNCH(ctx, "k_tile_hist", k_tile_hist, dim3(grid_tiles), dim3(GASM_WG), (size_t)rt * 4 * nb * 4, rs, k, bbits, g, tr, orr, rd.n_tiles,
-                bs.d_cube.as<u16>());
+        if (W == 1) {
+            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_WG), (size_t)rt * 4 * nb * 4, rs, k, bbits, g, tr, orr,
+                    rd.n_tiles, bs.d_cube.as<u16>());
+        } else {
+            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_WG), (size_t)rt * 4 * nb * 4, rs, k, bbits, g, tr, orr,
+                    rd.n_tiles, bs.d_cube.as<u16>());
+        }
         GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(std::min(1024u, std::max(64u, nb))), 0, rs, bbits, rt * 4, bs.d_cube.as<u16>(),
                 bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
-        const size_t lds = (size_t)GASM_KT * 64 * 4 * 8 + (size_t)nb * 48 + 64;
+        const size_t lds = (size_t)KT * 64 * 4 * KB + (size_t)nb * 48 + 64;
         const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 64));
-        GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter, dim3(grid_scatter), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
-                bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), dbg_s);
+        if (W == 1) {
+            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), dbg_s);
+        } else {
+            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<K128>(), dbg_s);
+        }
         unsigned long long* d_stamps = nullptr;
         static DBuf stamp_buf;
         if (getenv("GASM_DBG_STAMPS")) {   // diagnostic: per-phase cycle totals of k_bucket_dedup to stderr
             int o1 = 0, o2 = 0, o3 = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_bucket_dedup<2048>, GASM_WG, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_bucket_dedup<4096>, GASM_WG, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, k_bucket_scatter, GASM_WG, (size_t)GASM_KT * 64 * 4 * 8 + (size_t)nb * 48 + 64);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_bucket_dedup<u64, 2048>, GASM_WG, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_bucket_dedup<u64, 4096>, GASM_WG, 0);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, k_bucket_scatter<u64>, GASM_WG, (size_t)GASM_KT * 64 * 4 * 8 + (size_t)nb * 48 + 64);
             fprintf(stderr, "[occupancy API] dedup<2048> %d  dedup<4096> %d  scatter %d blocks/CU\n", o1, o2, o3);
             GCHK(stamp_buf.ensure(64 + (size_t)nbt * 24));
             HIPCHK(hipMemsetAsync(stamp_buf.p, 0, 64 + (size_t)nbt * 24, ctx->stream));
@@ -320,11 +337,14 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         bs.fbits = small_tbl ? 9 : 10;   // bins of the de-duplication kernel's counting sort = TBL / 4
         GCHK(bs.d_fdir.ensure((size_t)nbt * ((1u << bs.fbits) + 1) * 2));
         HIPCHK(hipMemsetAsync(bs.d_fdir.p, 0, (size_t)nbt * ((1u << bs.fbits) + 1) * 2, ctx->stream));
-        if (small_tbl) {
-            GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup<2048>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+        if (W == 2) {
+            GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<K128, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
+                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+        } else if (small_tbl) {
+            GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
                     bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
         } else {
-            GLAUNCH(ctx, "k_bucket_dedup", k_bucket_dedup<4096>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+            GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 4096>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
                     bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
         }
         if (d_stamps) {
@@ -346,7 +366,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         hflags[0] = bs.h_dstart[(size_t)nbt + 1];
         bs.h_dstart.resize((size_t)nbt + 1);
         if (!hflags[0]) break;
-        if (small_tbl) { small_tbl = false; continue; }   // same partition, larger tables
+        if (small_tbl && W == 1) { small_tbl = false; continue; }   // same partition, larger tables
         if (bbits >= bb_cap) {
             gasm_set_error("a k-mer bucket holds more than %d distinct k-mers even with %d bucket bits", GASM_TBL_LIMIT, bbits);
             return GASM_ERR_CAPACITY;
@@ -362,10 +382,15 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     bs.h_seg_cstart.assign((size_t)S + 1, 0);
     bs.h_seg_bstart.assign((size_t)S + 1, 0);
     if (D == 0) return GASM_OK;
-    GCHK(bs.d_dk_key.ensure((size_t)D * 8));
+    GCHK(bs.d_dk_key.ensure((size_t)D * KB));
     GCHK(bs.d_dk_cnt.ensure((size_t)D * 4));
-    GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-            bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<u64>(), bs.d_dk_cnt.as<u32>());
+    if (W == 1) {
+        GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<u64>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<u64>(), bs.d_dk_cnt.as<u32>());
+    } else {
+        GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<K128>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
+                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<K128>(), bs.d_dk_cnt.as<u32>());
+    }
     // ---- graph
     GCHK(bs.d_eflag.ensure(D));
     GCHK(bs.d_nxt.ensure((size_t)D * 4));
@@ -378,7 +403,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     HIPCHK(hipMemsetAsync(bs.d_link.p, 0xFF, (size_t)D * 8, ctx->stream));
     HIPCHK(hipMemsetAsync(bs.d_clen.p, 0, (size_t)D * 4, ctx->stream));
     GraphView gv;
-    gv.dk_key = bs.d_dk_key.as<u64>();
+    gv.dk_key = bs.d_dk_key.p;
     gv.dstart = bs.d_dstart.as<u32>();
     gv.fdir = bs.d_fdir.as<u16>();
     gv.k = k;
@@ -386,19 +411,17 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     gv.fbits = bs.fbits;
     const dim3 grid_seg(ceil_div_u64(maxD, GASM_WG), S);
     const dim3 grid_all(ceil_div_u64(D, GASM_WG));
-    GLAUNCH(ctx, "k_node_flags", k_node_flags, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>());
-    GLAUNCH(ctx, "k_edge_next", k_edge_next, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
+    if (W == 1) {
+        GLAUNCH(ctx, "k_node_flags", k_node_flags<u64>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>());
+        GLAUNCH(ctx, "k_edge_next", k_edge_next<u64>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
+    } else {
+        GLAUNCH(ctx, "k_node_flags", k_node_flags<K128>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>());
+        GLAUNCH(ctx, "k_edge_next", k_edge_next<K128>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
+    }
     int rounds = 1;
     while ((1ull << rounds) < (u64)maxD) ++rounds;
     rounds += 1;
-    const int rank_mode = getenv("GASM_RANK_MODE") ? atoi(getenv("GASM_RANK_MODE")) : 1;
-    if (rank_mode == 2 && maxD <= (1u << 22)) {
-        // ruling set: anchors walk to the next anchor, anchors are ranked by pointer doubling inside one workgroup per
-        // segment, anchors walk again and rank the edges between them
-        GLAUNCH(ctx, "k_rank_walk", k_rank_walk, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>(), D, 1);
-        GLAUNCH(ctx, "k_rank_anchors", k_rank_anchors, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), rounds + 1);
-        GLAUNCH(ctx, "k_rank_walk", k_rank_walk, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>(), D, 3);
-    } else if (maxD <= (1u << 18)) {
+    if (maxD <= (1u << 18)) {
         // one workgroup per segment runs every round (early exit); enough for segments up to 256k distinct k-mers
         GLAUNCH(ctx, "k_link_rank_seg", k_link_rank_seg, dim3(S), dim3(1024), 0, gv, bs.d_link.as<u64>(), rounds + 1);
     } else {
@@ -428,8 +451,13 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     }
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, ctx->stream, bs.d_c_off.as<u64>() + bs.n_contigs, bs.contig_bases);
     if (bs.n_contigs) {
-        GLAUNCH(ctx, "k_contig_emit", k_contig_emit, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
-                bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), D);
+        if (W == 1) {
+            GLAUNCH(ctx, "k_contig_emit", k_contig_emit<u64>, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
+                    bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), D);
+        } else {
+            GLAUNCH(ctx, "k_contig_emit", k_contig_emit<K128>, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
+                    bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), D);
+        }
     }
     return GASM_OK;
 }
@@ -439,10 +467,10 @@ int pipeline_fetch_distinct(gasm_ctx* ctx, const DevReads& rd, BuildState& bs) {
     const u32 S = rd.n_segments, nb = 1u << bs.bbits;
     bs.h_seg_doff.resize((size_t)S + 1);
     for (u32 s = 0; s <= S; ++s) bs.h_seg_doff[s] = bs.h_dstart.empty() ? 0 : bs.h_dstart[(size_t)s * nb];
-    bs.h_dk_key.resize(bs.d_total);
+    bs.h_dk_key.resize((size_t)bs.d_total * bs.words);     // 128-bit keys come back as (hi, lo) pairs
     bs.h_dk_cnt.resize(bs.d_total);
     if (bs.d_total) {
-        HIPCHK(hipMemcpyAsync(bs.h_dk_key.data(), bs.d_dk_key.p, (size_t)bs.d_total * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(bs.h_dk_key.data(), bs.d_dk_key.p, (size_t)bs.d_total * 8 * bs.words, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(bs.h_dk_cnt.data(), bs.d_dk_cnt.p, (size_t)bs.d_total * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -592,7 +620,7 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
         // the paths are this build's contigs and every read holds a k-mer: the sorted edge list is the index, and the
         // per-path sums are accumulated per read in fixed point (no position counters)
         GraphView gv;
-        gv.dk_key = graph->d_dk_key.as<u64>();
+        gv.dk_key = graph->d_dk_key.p;
         gv.dstart = graph->d_dstart.as<u32>();
         gv.fdir = graph->d_fdir.as<u16>();
         gv.k = graph->k;
@@ -603,10 +631,16 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
         GCHK(const_cast<ScoreTable&>(tb).set_fixed(ctx, max_reads));
         GCHK(ss.d_fxsum.ensure(((size_t)P + 1) * 8));
         HIPCHK(hipMemsetAsync(ss.d_fxsum.p, 0, ((size_t)P + 1) * 8, ctx->stream));
-        const u32 reads_per_wg = 2048;
-        GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph, dim3(ceil_div_u64(max_reads, reads_per_wg), S), dim3(GASM_WG), 0, rd.view(), gv,
-                graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, ss.d_total.as<u32>(),
-                ss.d_fxsum.as<unsigned long long>());
+        const u32 reads_per_wg = 256;     // one read per thread: the match is a chain of dependent loads
+        if (graph->words == 1) {
+            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<u64>, dim3(ceil_div_u64(max_reads, reads_per_wg), S), dim3(GASM_WG), 0, rd.view(),
+                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, ss.d_total.as<u32>(),
+                    ss.d_fxsum.as<unsigned long long>());
+        } else {
+            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<K128>, dim3(ceil_div_u64(max_reads, reads_per_wg), S), dim3(GASM_WG), 0, rd.view(),
+                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, ss.d_total.as<u32>(),
+                    ss.d_fxsum.as<unsigned long long>());
+        }
     } else if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
         // per-segment seed tables: power-of-two, at least twice the number of path positions
         std::vector<u64>& toff = ss.h_toff;

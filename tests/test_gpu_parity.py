@@ -72,7 +72,7 @@ def test_get_contigs_reference_operating_points(read_len, k):
     assert ga.assemble_contigs(m, k) == orc.assemble_contigs(ref["contigs"], ref["perm"], k)
 
 
-@pytest.mark.parametrize("k", [2, 3, 5, 11, 21, 31])
+@pytest.mark.parametrize("k", [2, 3, 5, 11, 21, 31, 32, 33, 41, 51, 63])
 def test_get_contigs_k_range_with_repeats(k):
     g = synth.make_segment(7 + k, 6000, n_short=6, short_len=120, n_long=2, long_len=500, tandem_len=200, planted=True)
     reads = _strs(synth.simulate_reads(g, max(k + 9, 40), 15, 3))
@@ -112,7 +112,8 @@ def test_non_acgt_is_rejected():
 
 
 # ------------------------------------------------------------------------------------------------ batches
-@pytest.mark.parametrize("n_seg,L,rl,cov,k", [(4, 5000, 100, 20, 21), (3, 8000, 150, 25, 31), (5, 1500, 40, 30, 15)])
+@pytest.mark.parametrize("n_seg,L,rl,cov,k", [(4, 5000, 100, 20, 21), (3, 8000, 150, 25, 31), (5, 1500, 40, 30, 15),
+                                              (3, 6000, 250, 30, 51), (2, 4000, 120, 20, 32)])
 def test_batch_build_and_score_against_oracle(qtable, n_seg, L, rl, cov, k):
     keys, prob = qtable
     reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, cov, seed0=900 + k, planted=True)
@@ -207,19 +208,21 @@ def test_calc_breakscore_window_edges_and_duplicates(qtable):
 
 
 # ------------------------------------------------------------------------------------------------ full-size properties
-def test_full_size_segment_properties(qtable):
-    """BASELINE config 2 shape (50 kb, 100 bp, 50x, k=31) without the oracle: size-independent properties."""
+@pytest.mark.parametrize("k,rl,cov", [(31, 100, 50), (51, 250, 100)])
+def test_full_size_segment_properties(qtable, k, rl, cov):
+    """BASELINE configs[1] (50 kb, 100 bp, 50x, k=31) and configs[4] (250 bp, 100x, k=51: 128-bit keys) shapes without the
+    oracle: size-independent properties."""
     _, prob = qtable
-    k, rl = 31, 100
-    reads, seg_off, genomes = synth.make_batch(2, 50000, rl, 50, seed0=4242, planted=True)
+    reads, seg_off, genomes = synth.make_batch(2, 50000, rl, cov, seed0=4242, planted=True)
     b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
     b.build(k, genome_len_hint=50000).score(8, prob)
     seg, keys_, mult, w = b.distinct()
     sc = b.scores()
     for s in range(2):
         a, e = int(seg[s]), int(seg[s + 1])
-        ks = keys_[a:e]
-        assert (np.diff(ks.astype(object)) > 0).all()                      # sorted, distinct
+        ks = keys_[a * w:e * w].reshape(-1, w)
+        big = [int(r[0]) if w == 1 else (int(r[0]) << 64) | int(r[1]) for r in ks]
+        assert all(x < y for x, y in zip(big, big[1:]))                     # sorted, distinct
         assert int(mult[a:e].sum()) == (int(seg_off[s + 1]) - int(seg_off[s])) * (rl - k + 1)   # every k-mer counted once
         cs = b.contigs(s)
         assert cs == sorted(set(cs))                                       # canonical order
