@@ -34,6 +34,7 @@ WORKLOADS = {
     "cfg2": (100, 50000, 150, 50, 31),   # BASELINE.json configs[2]
     "cfg1": (1, 50000, 100, 50, 31),     # BASELINE.json configs[1]
     "cfg0": (1, 50000, 100, 20, 21),     # BASELINE.json configs[0]
+    "cfg4": (100, 50000, 250, 100, 51),  # BASELINE.json configs[4] shape per GPU (128-bit keys; its "guided traversal" has no reference)
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
@@ -109,11 +110,12 @@ def main():
     # ---- roofline of the dominant kernel (HIP events on the library's stream, timed steps only)
     seg, keys, mult, _w = batch.distinct()
     n_distinct = int(seg[-1])
+    key_bytes = 8.0 if k <= 31 else 16.0      # W of SURVEY §8(d)
     alg_bytes = {
-        # read packed bases 0.25*rl/(rl-k+1) B per k-mer + write the 8-byte key to its bucket
-        "k_bucket_scatter": n_kmers * (8.0 + 0.25 * rl / (rl - k + 1)),
-        # read the key back (8 B per k-mer) + write (key, multiplicity) per distinct k-mer
-        "k_bucket_dedup": n_kmers * 8.0 + n_distinct * 12.0,
+        # read packed bases 0.25*rl/(rl-k+1) B per k-mer + write the W-byte key to its bucket
+        "k_bucket_scatter": n_kmers * (key_bytes + 0.25 * rl / (rl - k + 1)),
+        # read the key back (W bytes per k-mer) + write (key, multiplicity) per distinct k-mer
+        "k_bucket_dedup": n_kmers * key_bytes + n_distinct * (key_bytes + 4.0),
     }
     dom = max(dominant, key=lambda n: prof.get(n, (0.0, 0))[0])
     ms, launches = prof.get(dom, (0.0, 0))
@@ -167,7 +169,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u64 keys / u32 counts / f64 scores",
+            "dtype": ("u64" if k <= 31 else "u128") + " keys / u32 counts / f64 scores",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {nseg} x {L} bp segments per GPU, {rl} bp reads at {cov}x, k={k}, "
                                    "build + breakage scoring of all contigs", "segments_total": nseg * world,
