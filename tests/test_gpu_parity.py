@@ -134,6 +134,46 @@ def test_batch_build_and_score_against_oracle(qtable, n_seg, L, rl, cov, k):
     b.close()
 
 
+def test_overflow_retry_and_skewed_bins():
+    """Paths the tuned defaults never take: (a) a far too small genome_len_hint -> one bucket -> table overflow ->
+    4096-slot table -> more bucket bits (host retry loop); (b) a two-letter genome -> all keys of a bucket fall into a
+    few counting-sort bins -> bitonic fallback of the de-duplication kernel; (c) 128-bit keys through the same."""
+    rng = np.random.default_rng(77)
+    for k, rl, alphabet in [(21, 60, b"ACGT"), (31, 80, b"AC"), (41, 100, b"AC"), (15, 40, b"CT")]:
+        g = np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), 12000)]
+        reads = synth.simulate_reads(g, rl, 12, 5)
+        seg_off = np.array([0, reads.shape[0]], dtype=np.uint64)
+        rs = _strs(reads)
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+        for hint in (50, 0, 12000):
+            b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+            b.build(k, genome_len_hint=hint)
+            assert b.contigs(0) == ref["contigs"], (k, alphabet, hint)
+            dk, dm = b.distinct_kmers(0)
+            assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist(), (k, alphabet, hint)
+            b.close()
+
+
+def test_high_multiplicity_and_homopolymers(qtable):
+    """tandem repeats and homopolymer runs: one k-mer thousands of times in a bucket (same-address LDS atomics), nodes with
+    self-loops, reads that are all the same string"""
+    keys, prob = qtable
+    unit = "ACGGTC"
+    g = "TTGACCA" * 30 + unit * 400 + "A" * 300 + "GATTACA" * 50 + "C" * 200 + "ACGT" * 100
+    rl, k = 70, 25
+    reads = [g[i:i + rl] for i in range(0, len(g) - rl + 1, 3)] + [g[500:500 + rl]] * 500
+    b = ga.SegmentBatch.from_strings([reads])
+    b.build(k).score(8, prob)
+    ref = orc.get_contigs(orc.kmers_from_reads(reads, k), k, 1, rows=1)
+    assert b.contigs(0) == ref["contigs"]
+    dk, dm = b.distinct_kmers(0)
+    assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist()
+    o = orc.calc_breakscore(ref["contigs"], reads, g, 8, keys, prob, with_lev=False, with_freq=False)
+    sc = b.scores()
+    _check_scores({kk: v for kk, v in sc.items() if kk != "seg_contig_off"}, o, with_lev=False)
+    b.close()
+
+
 def test_batch_ragged_reads_and_empty_segment():
     rng = np.random.default_rng(3)
     g = _strs(synth.make_segment(5, 3000, planted=False)[None, :])[0]
