@@ -39,15 +39,19 @@ __device__ __forceinline__ u32 hash64(u64 x) { return (u32)((x * 0x9E3779B97F4A7
 // Block-wide exclusive scan of one u32 per thread, GASM_WG (=256) threads = 4 waves.  s_tmp: >= 5 u32 of LDS.
 // Returns the exclusive prefix; *total gets the block sum.  Contains two barriers.
 // ----------------------------------------------------------------------------------------------------------------
+// Inclusive scan across the 64 lanes in the VALU's DPP network (row shifts inside rows of 16, then row broadcasts):
+// no LDS round trips, unlike __shfl_up (ds_bpermute).  Lanes without a source add 0.
 __device__ __forceinline__ u32 wave_incl_scan(u32 v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return v;
 }
+// the value of lane 63 (e.g. the total after wave_incl_scan), uniform
+__device__ __forceinline__ u32 wave_last(u32 v) { return (u32)__builtin_amdgcn_readlane((int)v, 63); }
 
 template <int NT>
 __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* s_tmp, u32* total) {

@@ -12,6 +12,8 @@ struct ReadSet {
     const u64* read_off;       // n_reads+1 base offsets, or nullptr when fixed_len > 0
     const u64* seg_read_off;   // n_segments+1 read indices
     const u32* seg_tile_start; // n_segments+1 tile indices (depends on the tile width of the launch)
+    const uint4* tile_info;    // per tile {segment, reads in the tile, first read lo, first read hi}: one 16-byte load instead
+                               // of a binary search of dependent loads at the head of every tile
     u32 fixed_len;
     u32 n_segments;
 };
@@ -72,7 +74,7 @@ template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
 __global__ void k_copy_u64(const u64* a, u64* b, u32 n);
 template <class K>
 __global__ void k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles, const u64* bstart,
-                                 const u32* toff, const u16* cube, K* keys, int dbg);
+                                 const u32* toff, const u16* cube, K* keys, u64 scratch, unsigned long long* stamps);
 #define GASM_RT_MAX 16      // rounds (read groups x offset rounds) one scatter tile may hold
 template <class K, int TBL>
 __global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits, int dbg,

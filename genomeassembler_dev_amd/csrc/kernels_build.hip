@@ -61,12 +61,11 @@ __global__ void __launch_bounds__(GASM_WG) k_pack_ascii(const u8* __restrict__ a
 struct TileInfo { u32 seg; u64 r0; u32 nitems; };
 
 __device__ __forceinline__ TileInfo tile_decode(const ReadSet& rs, u32 tile, u32 ipt) {
+    const uint4 e = rs.tile_info[tile];        // uniform across the workgroup: a scalar load
     TileInfo ti;
-    ti.seg = upper_seg<u32>(rs.seg_tile_start, rs.n_segments, tile);
-    const u64 first = rs.seg_read_off[ti.seg] + (u64)(tile - rs.seg_tile_start[ti.seg]) * ipt;
-    const u64 left = rs.seg_read_off[ti.seg + 1] - first;
-    ti.r0 = first;
-    ti.nitems = (u32)(left < ipt ? left : ipt);
+    ti.seg = e.x;
+    ti.nitems = e.y;
+    ti.r0 = (u64)e.z | ((u64)e.w << 32);
     return ti;
 }
 
@@ -194,11 +193,27 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// makes the compiler wait for pending loads of these registers at this point
+__device__ __forceinline__ void touch_regs(u32 a, u32 b, u32 c, u32 d, u32 e, u32 f, u32 g, u32 h, u32 i, u32 j) {
+    __asm__ volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h), "v"(i), "v"(j));
+}
+
 template <class K>
-__global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles,
+__global__ void __launch_bounds__(GASM_WG, 4) k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles,
                                                             const u64* __restrict__ bstart, const u32* __restrict__ toff,
-                                                            const u16* __restrict__ cube, K* __restrict__ keys, int dbg) {
+                                                            const u16* __restrict__ cube, K* __restrict__ keys, u64 scratch,
+                                                            unsigned long long* __restrict__ stamps) {
     extern __shared__ __align__(16) unsigned char s_raw[];
+    // diagnostic build only (-DGASM_SCATTER_STAMPS): shader-clock totals of wave 0 per phase, summed over workgroups.
+    // Compiled out otherwise — the accumulators cost 14 registers, and the kernel sits right at 128.
+#ifdef GASM_SCATTER_STAMPS
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto phase = [&](int i) {
+        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tacc[i] += t - tlast; tlast = t; }
+    };
+#else
+    auto phase = [](int) {};
+#endif
     constexpr u32 KT = KeyTraits<K>::KT;
     constexpr u32 WSTAGE = KT * 64;
     const u32 rt = tr * orr, rt4 = rt * 4;
@@ -224,6 +239,27 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, i
             cw[0] = v0.x; cw[1] = v0.y; cw[2] = v0.z; cw[3] = v0.w; cw[4] = v1.x; cw[5] = v1.y; cw[6] = v1.z; cw[7] = v1.w;
             tbase = bstart[(u64)ti.seg * nb + ln] + toff[(u64)tile * nb + ln];
         }
+        // the words a thread needs in round q, and how many of its KT starts are k-mers
+        auto fetch_round = [&](u32 q, Roll<K>& r, u32& nv) {
+            const u32 t = q / orr, o = q - t * orr;
+            const u32 it = t * ipt + item;
+            u64 p0 = 0; u32 nk = 0;
+            if (it < ti.nitems) {
+                u32 len;
+                read_span(rs, ti.r0 + it, &p0, &len);
+                nk = len >= (u32)k ? len - k + 1 : 0;
+            }
+            const u32 off0 = o * g * KT + lane * KT;
+            nv = off0 < nk ? min(nk - off0, KT) : 0u;
+            r.load(rs.words, nv ? p0 + off0 : 0);
+        };
+        Roll<K> rl;
+        u32 nv;
+        fetch_round(0, rl, nv);
+        // Every load so far is waited for here, once, outside the round loop: a wait placed inside the loop would also
+        // cover the loop's own stores (see the note at the prefetch below).
+        touch_regs(cw[0], cw[1], cw[2], cw[3], cw[4], cw[5], cw[6], cw[7], (u32)tbase, (u32)(tbase >> 32));
+        rl.touch();
         // filler behind the tile's run of every bucket, up to the next 128-byte line (the de-duplication skips it)
         if (wv == 0) {
             for (u32 b = ln; b < nb; b += 64) {
@@ -242,6 +278,7 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, i
             }
         }
         u32 run_before = 0;   // fast path: k-mers of this lane's bucket in earlier rounds (all waves)
+        phase(0);
         for (u32 q = 0; q < rt; ++q) {
             // ---- where this wave's k-mers of round q go, bucket by bucket
             u32 kcar = 0;
@@ -272,48 +309,70 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_scatter(ReadSet rs, int k, i
                     s_cur[b] = off;
                     s_comb[b] = base - off;                          // global index = s_comb[bucket] + staging index
                 }
-                kcar += __shfl(inc, 63, 64);
+                kcar += wave_last(inc);
             }
             const u32 staged = kcar;
             wave_sync_lds();
+            phase(1);
             // ---- rank and stage.  The ds_add_rtn of a thread are issued back to back (a position past the end of the read
             // ranks into a dummy bin) and waited for once; a branch per k-mer would make them dependent LDS round trips.
-            const u32 t = q / orr, o = q - t * orr;
-            const u32 it = t * ipt + item;
-            u64 p0 = 0; u32 nk = 0;
-            if (it < ti.nitems) {
-                u32 len;
-                read_span(rs, ti.r0 + it, &p0, &len);
-                nk = len >= (u32)k ? len - k + 1 : 0;
-            }
-            const u32 off0 = o * g * KT + lane * KT;
-            const bool any = off0 < nk;
-            Roll<K> rl;
-            rl.load(rs.words, any ? p0 + off0 : 0);
+            // the words of this round were requested before the previous round's KT stores (first round: already waited for)
+            rl.template wait_all_but<KT>();
             K key[KT];
             u32 idx[KT];
+#ifdef GASM_SCATTER_STAMPS
+            if (stamps) { key[0] = rl.key(0, k); if (kis_empty(key[0])) tacc[5] += 1; phase(2); }   // words have arrived
+#endif
 #pragma unroll
             for (u32 j = 0; j < KT; ++j) {
                 key[j] = rl.key(j, k);
                 const u32 bkt = bbits ? (u32)(rl.top(j) >> (64 - bbits)) : 0u;
-                idx[j] = atomicAdd(&s_cur[(any && off0 + j < nk) ? bkt : nb], 1u);
+                idx[j] = atomicAdd(&s_cur[j < nv ? bkt : nb], 1u);
             }
+            // The next round's words are requested now, ahead of this round's stores: memory operations of a wave
+            // retire in order (one counter for loads and stores), so a load issued after the stores would wait for all
+            // of them.  The flush below issues exactly KT stores whatever `staged` is — the wait for these words can
+            // then be "all but the last KT operations" instead of "everything".
+            Roll<K> rn;
+            u32 nvn;
+            fetch_round(min(q + 1, rt - 1), rn, nvn);
+#ifdef GASM_SCATTER_STAMPS
+            if (stamps) { if (idx[KT - 1] == 0xFFFFFFFFu) tacc[5] += 1; phase(3); }                  // atomics have returned
+#endif
 #pragma unroll
             for (u32 j = 0; j < KT; ++j)
-                if (any && off0 + j < nk) s_key[idx[j]] = key[j];
+                if (j < nv) s_key[idx[j]] = key[j];
             wave_sync_lds();
-            // ---- stream out
-            if (dbg != 2) for (u32 i = ln; i < staged; i += 64) {
-                const K kk = s_key[i];
-                const u32 bkt = bbits ? kfield(kk, bshift) : 0u;
-                keys[s_comb[bkt] + i] = kk;
+            phase(4);
+            // ---- stream out, four keys per thread at a time (their LDS reads overlap); lanes past the end store to a
+            // scratch line behind the key array instead of branching
+#pragma unroll
+            for (u32 u0 = 0; u0 < KT; u0 += 4) {
+                K kk[4];
+                u64 cb[4];
+#pragma unroll
+                for (u32 u = 0; u < 4; ++u) kk[u] = s_key[ln + 64 * (u0 + u)];
+#pragma unroll
+                for (u32 u = 0; u < 4; ++u) cb[u] = s_comb[bbits ? (kfield(kk[u], bshift) & (nb - 1)) : 0u];
+#pragma unroll
+                for (u32 u = 0; u < 4; ++u) {
+                    const u32 i = ln + 64 * (u0 + u);
+                    keys[i < staged ? cb[u] + i : scratch + ln] = kk[u];
+                }
             }
             wave_sync_lds();
+            phase(5);
+            rl = rn;
+            nv = nvn;
         }
     }
+#ifdef GASM_SCATTER_STAMPS
+    if (stamps && threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&stamps[i], tacc[i]);
+#endif
 }
-template __global__ void k_bucket_scatter<u64>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, const u16*, u64*, int);
-template __global__ void k_bucket_scatter<K128>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, const u16*, K128*, int);
+template __global__ void k_bucket_scatter<u64>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, const u16*, u64*, u64, unsigned long long*);
+template __global__ void k_bucket_scatter<K128>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, const u16*, K128*, u64, unsigned long long*);
 
 // ================================================================================================================
 // De-duplicate one bucket: stream its keys through an LDS table (count per distinct key), then order the distinct keys
@@ -418,31 +477,30 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }  // [4] distinct so far, [5] overflow, [6] longest bin
     __syncthreads();
     phase(0);
-    auto insert = [&](const K& key) {
-        u32 set = khash(key) >> (32 - LOG_SETS);
-        for (u32 probe = 0; probe < 8 * NSETS; ++probe) if (dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, set)) return;
-        s_tmp[5] = 1;
-    };
     // stream: four 16-byte loads per thread in flight (the loop is latency-bound otherwise), each fully coalesced across
     // the wave.  Bucket ranges start and end on 128-byte lines (filler keys = EMPTY are skipped).
     constexpr int KPL = 64 / sizeof(K);          // keys per thread and iteration: 8 or 4
     const u64 nch = n * sizeof(K) / 16;          // 16-byte chunks in the bucket
     const uint4* src = reinterpret_cast<const uint4*>(keys + beg);
+    // the loads of the next iteration are issued before this iteration's keys go into the table, so the table work
+    // (LDS latency) and the HBM latency overlap inside every wave
+    uint4 v[4];
+    auto fetch = [&](u64 c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = c + (u64)q * GASM_WG < nch ? src[c + (u64)q * GASM_WG] : make_uint4(~0u, ~0u, ~0u, ~0u);
+    };
+    if (threadIdx.x < nch) fetch(threadIdx.x);
     for (u64 c = threadIdx.x; c < nch; c += 4 * GASM_WG) {
         if (c == (u64)threadIdx.x + 4 * GASM_WG) phase(1);   // first iteration (table fill) done
         K kx[KPL];
-        {
-            uint4 v[4];
+        if constexpr (WIDE) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = c + (u64)q * GASM_WG < nch ? src[c + (u64)q * GASM_WG] : make_uint4(~0u, ~0u, ~0u, ~0u);
-            if constexpr (WIDE) {
+            for (int q = 0; q < 4; ++q) { kx[q].hi = (u64)v[q].x | ((u64)v[q].y << 32); kx[q].lo = (u64)v[q].z | ((u64)v[q].w << 32); }
+        } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { kx[q].hi = (u64)v[q].x | ((u64)v[q].y << 32); kx[q].lo = (u64)v[q].z | ((u64)v[q].w << 32); }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { kx[2 * q] = (u64)v[q].x | ((u64)v[q].y << 32); kx[2 * q + 1] = (u64)v[q].z | ((u64)v[q].w << 32); }
-            }
+            for (int q = 0; q < 4; ++q) { kx[2 * q] = (u64)v[q].x | ((u64)v[q].y << 32); kx[2 * q + 1] = (u64)v[q].z | ((u64)v[q].w << 32); }
         }
+        if (c + 4 * GASM_WG < nch) fetch(c + 4 * GASM_WG);
         if ((dbg & 3) == 1) { u64 x = 0; for (int q = 0; q < KPL; ++q) x ^= khash(kx[q]); if (x == 0x1234567) s_tmp[6] = 1; continue; }
         if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { s_tmp[5] = 1; break; }
         if constexpr (!WIDE) {

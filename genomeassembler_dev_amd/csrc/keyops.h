@@ -84,6 +84,13 @@ template <> struct Roll<u64> {
         return (x << o) | ((y >> 1) >> (63 - o));
     }
     __device__ __forceinline__ u64 key(u32 j, int k) const { return top(j) >> (64 - 2 * k); }
+    // makes the compiler wait for the loaded words here
+    __device__ __forceinline__ void touch() const { __asm__ volatile("" :: "v"(w0), "v"(w1), "v"(w2)); }
+    // explicit wait for words requested N vector-memory operations before the most recent one (memory operations of a
+    // wave retire in order); every later use of the words depends on this statement
+    template <int N> __device__ __forceinline__ void wait_all_but() {
+        __asm__ volatile("s_waitcnt vmcnt(%3)" : "+v"(w0), "+v"(w1), "+v"(w2) : "n"(N) : "memory");
+    }
 };
 template <> struct Roll<K128> {
     u64 w0, w1, w2, w3;
@@ -107,6 +114,10 @@ template <> struct Roll<K128> {
         const u32 o = ob & 63;
         const K128 win{hi ? word(o, w1, w2) : word(o, w0, w1), hi ? word(o, w2, w3) : word(o, w1, w2)};
         return kshr(win, 128 - 2 * k);
+    }
+    __device__ __forceinline__ void touch() const { __asm__ volatile("" :: "v"(w0), "v"(w1), "v"(w2), "v"(w3)); }
+    template <int N> __device__ __forceinline__ void wait_all_but() {
+        __asm__ volatile("s_waitcnt vmcnt(%4)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3) : "n"(N) : "memory");
     }
 };
 

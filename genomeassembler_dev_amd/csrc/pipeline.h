@@ -16,8 +16,8 @@ struct DevReads {
     DBuf d_words, d_read_off, d_seg_read_off;
     // tile directory cache (depends on reads per tile)
     u32 tiles_ipt = 0, n_tiles = 0;
-    std::vector<u32> h_seg_tile_start;
-    DBuf d_seg_tile_start;
+    std::vector<u32> h_seg_tile_start, h_tile_info;
+    DBuf d_seg_tile_start, d_tile_info;
 
     int upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off,
                u32 n_segments);

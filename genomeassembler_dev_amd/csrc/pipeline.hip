@@ -119,6 +119,16 @@ int DevReads::set_tiles(gasm_ctx* ctx, u32 ipt) {
     }
     GCHK(h2d(ctx, d_seg_tile_start, t.data(), t.size() * 4));
     n_tiles = t[n_segments];
+    std::vector<u32>& info = h_tile_info;
+    info.assign((size_t)n_tiles * 4 + 4, 0);
+    for (u32 s = 0; s < n_segments; ++s)
+        for (u32 tile = t[s]; tile < t[s + 1]; ++tile) {
+            const u64 first = h_seg_read_off[s] + (u64)(tile - t[s]) * ipt;
+            const u64 left = h_seg_read_off[s + 1] - first;
+            u32* e = &info[(size_t)tile * 4];
+            e[0] = s; e[1] = (u32)std::min<u64>(left, ipt); e[2] = (u32)first; e[3] = (u32)(first >> 32);
+        }
+    GCHK(h2d(ctx, d_tile_info, info.data(), info.size() * 4));
     tiles_ipt = ipt;
     return GASM_OK;
 }
@@ -129,12 +139,13 @@ ReadSet DevReads::view() const {
     v.read_off = fixed_len ? nullptr : d_read_off.as<u64>();
     v.seg_read_off = d_seg_read_off.as<u64>();
     v.seg_tile_start = d_seg_tile_start.as<u32>();
+    v.tile_info = d_tile_info.as<uint4>();
     v.fixed_len = fixed_len;
     v.n_segments = n_segments;
     return v;
 }
 
-void DevReads::release() { d_words.release(); d_read_off.release(); d_seg_read_off.release(); d_seg_tile_start.release(); }
+void DevReads::release() { d_words.release(); d_read_off.release(); d_seg_read_off.release(); d_seg_tile_start.release(); d_tile_info.release(); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // DevPaths
@@ -261,7 +272,6 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         if (getenv("GASM_DEDUP_TBL")) small_tbl = atoi(getenv("GASM_DEDUP_TBL")) == 2048;
         if (W == 2) small_tbl = true;         // 128-bit keys: 2048-slot tables only
     }
-    const int dbg_s = getenv("GASM_DBG_SCATTER") ? atoi(getenv("GASM_DBG_SCATTER")) : 0;   // tuning ablations (wrong results!)
     const int dbg_d = getenv("GASM_DBG_DEDUP") ? atoi(getenv("GASM_DBG_DEDUP")) : 0;
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
@@ -290,11 +300,10 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         nbt = S * nb;
         GCHK(bs.d_hist.ensure((size_t)nbt * 4));
         GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 4));
-        {
-            const u64 n_alloc = std::min<u64>(n_pad_max, N + 16ull * rd.n_tiles * nb);
-            GCHK(bs.d_keys.ensure(n_alloc * KB));
-            GCHK(bs.d_mult.ensure(n_alloc * 4));
-        }
+        // (+ 64 keys of scratch behind the array: where k_bucket_scatter's idle lanes store)
+        const u64 n_alloc = std::min<u64>(n_pad_max, N + 16ull * rd.n_tiles * nb);
+        GCHK(bs.d_keys.ensure((n_alloc + 64) * KB));
+        GCHK(bs.d_mult.ensure(n_alloc * 4));
         GCHK(bs.d_cube.ensure((size_t)rd.n_tiles * nb * tr * orr * 4 * 2 + 64));
         GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
@@ -313,14 +322,31 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(std::min(1024u, std::max(64u, nb))), 0, rs, bbits, rt * 4, bs.d_cube.as<u16>(),
                 bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
-        const size_t lds = (size_t)KT * 64 * 4 * KB + (size_t)nb * 48 + 64;
+        size_t lds = (size_t)KT * 64 * 4 * KB + (size_t)nb * 48 + 64;
+        if (getenv("GASM_DBG_SCATTER_LDSPAD")) lds += (size_t)atoi(getenv("GASM_DBG_SCATTER_LDSPAD"));   // tuning: fewer workgroups per CU
         const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 64));
+        unsigned long long* d_sstamps = nullptr;
+        static DBuf sstamp_buf;
+        if (getenv("GASM_DBG_SCATTER_STAMPS")) {   // diagnostic: per-phase shader-clock totals of k_bucket_scatter (wave 0 of every workgroup)
+            GCHK(sstamp_buf.ensure(64));
+            HIPCHK(hipMemsetAsync(sstamp_buf.p, 0, 64, ctx->stream));
+            d_sstamps = sstamp_buf.as<unsigned long long>();
+        }
         if (W == 1) {
             GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), dbg_s);
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), n_alloc, d_sstamps);
         } else {
             GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<K128>(), dbg_s);
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<K128>(), n_alloc, d_sstamps);
+        }
+        if (d_sstamps) {
+            unsigned long long h[6];
+            HIPCHK(hipMemcpyAsync(h, d_sstamps, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            const double wr = (double)rd.n_tiles * tr * orr;   // wave-0 rounds in total
+            fprintf(stderr, "[scatter stamps, shader clocks per round of wave 0; %u workgroups] tile-prologue %.0f  bins %.0f  words-arrive %.0f  "
+                    "atomics %.0f  stage %.0f  flush+sync %.0f\n", grid_scatter, (double)h[0] / wr, (double)h[1] / wr, (double)h[2] / wr,
+                    (double)h[3] / wr, (double)h[4] / wr, (double)h[5] / wr);
         }
         unsigned long long* d_stamps = nullptr;
         static DBuf stamp_buf;
