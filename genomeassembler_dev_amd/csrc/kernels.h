@@ -12,8 +12,7 @@ struct ReadSet {
     const u64* read_off;       // n_reads+1 base offsets, or nullptr when fixed_len > 0
     const u64* seg_read_off;   // n_segments+1 read indices
     const u32* seg_tile_start; // n_segments+1 tile indices (depends on the tile width of the launch)
-    const uint4* tile_info;    // per tile {segment, reads in the tile, first read lo, first read hi}: one 16-byte load instead
-                               // of a binary search of dependent loads at the head of every tile
+    const uint4* tile_info;    // per tile {segment, reads in the tile, first read lo, first read hi (16 bits) | offset round << 16}
     u32 fixed_len;
     u32 n_segments;
 };
@@ -68,13 +67,14 @@ struct PathSet {
 
 // ---- kernels_build.hip
 __global__ void k_pack_ascii(const u8* ascii, u64 nbases, u64* words, u64 nwords, u32* err);
-template <class K> __global__ void k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles, u16* cube);
-__global__ void k_tile_scan(ReadSet rs, int bbits, u32 rt4, const u16* cube, u32* toff, u32* hist);
+#define GASM_TILE_WG 512    // threads of a tile workgroup (k_tile_hist, k_bucket_scatter)
+template <class K> __global__ void k_tile_hist(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 n_tiles, u16* tcnt);
+__global__ void k_tile_scan(ReadSet rs, int bbits, u32 padm, const u16* tcnt, u32* toff, u32* hist);
 template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
 __global__ void k_copy_u64(const u64* a, u64* b, u32 n);
 template <class K>
-__global__ void k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles, const u64* bstart,
-                                 const u32* toff, const u16* cube, K* keys, u64 scratch, unsigned long long* stamps);
+__global__ void k_bucket_scatter(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 padm, u32 n_tiles, const u64* bstart, const u32* toff,
+                                 const u16* tcnt, K* keys, u64 scratch);
 #define GASM_RT_MAX 16      // rounds (read groups x offset rounds) one scatter tile may hold
 template <class K, int TBL>
 __global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits, int dbg,

@@ -4,7 +4,7 @@
 //
 // What each kernel restates of the reference (paths relative to the reference root):
 //   k_pack_ascii      new surface (the reference keeps std::string)
-//   k_bucket_hist /
+//   k_tile_hist /
 //   k_bucket_scatter  lib/DeNovoAssembler.R:109-130 (every k-mer of every read) fused with the first half of the
 //                     de-duplication that lib/DeNovoAssembler.cpp:104-122 does through its hash map
 //   k_bucket_dedup    lib/DeNovoAssembler.cpp:104-122 (distinct edges) + multiplicities
@@ -55,17 +55,23 @@ __global__ void __launch_bounds__(GASM_WG) k_pack_ascii(const u8* __restrict__ a
 }
 
 // ================================================================================================================
-// Tiles.  A tile is up to `ipt` (= GASM_WG / g) consecutive reads of one segment; g threads share a read and take
-// k-mer start offsets lane, lane+g, ...  Segment of a tile: binary search in seg_tile_start (S+1 entries).
+// Tiles.  A tile is one workgroup-pass of the two tile kernels: up to ipt = GASM_TILE_WG / g consecutive reads of one
+// segment at one offset round o; the g threads that share a read take KT consecutive k-mer starts each, at offsets
+// o*g*KT + lane*KT + [0, KT) (KT = 16 for 64-bit keys, 8 for 128-bit keys; o > 0 only for reads with more than g*KT
+// k-mers).  The windows come out of a few 64-bit words held in registers (Roll<K>, keyops.h), so a k-mer costs a funnel
+// shift, not two loads.  The host builds the tile table (DevReads::set_tiles): one uniform 16-byte load per tile.
 // ================================================================================================================
-struct TileInfo { u32 seg; u64 r0; u32 nitems; };
+struct TileInfo { u32 seg; u64 r0; u32 nitems; u32 o; };
 
-__device__ __forceinline__ TileInfo tile_decode(const ReadSet& rs, u32 tile, u32 ipt) {
-    const uint4 e = rs.tile_info[tile];        // uniform across the workgroup: a scalar load
+// `tinfo` is the kernels' own __restrict__ copy of rs.tile_info: only then may the compiler use a scalar load (the
+// scalar cache is not coherent with the kernel's vector stores, so it needs the no-alias guarantee)
+__device__ __forceinline__ TileInfo tile_decode(const uint4* __restrict__ tinfo, u32 tile) {
+    const uint4 e = tinfo[tile];               // uniform across the workgroup
     TileInfo ti;
     ti.seg = e.x;
     ti.nitems = e.y;
-    ti.r0 = (u64)e.z | ((u64)e.w << 32);
+    ti.r0 = (u64)e.z | ((u64)(e.w & 0xFFFFu) << 32);
+    ti.o = e.w >> 16;
     return ti;
 }
 
@@ -74,83 +80,67 @@ __device__ __forceinline__ void read_span(const ReadSet& rs, u64 r, u64* p0, u32
     else { const u64 a = rs.read_off[r]; *p0 = a; *len = (u32)(rs.read_off[r + 1] - a); }
 }
 
-// Thread `lane` of the g threads that share a read takes KT consecutive k-mer starts per round: offsets
-// round*g*KT + lane*KT + [0, KT) (KT = 16 for 64-bit keys, 8 for 128-bit keys).  The windows come out of a few 64-bit
-// words held in registers (Roll<K>, keyops.h), so a k-mer costs a funnel shift, not two loads.
-
-// Count cube: for every tile, bucket, round q and wave w the number of k-mers wave w meets in round q of the tile
-// that fall into the bucket — cube[(tile * nb + b) * rt4 + q * 4 + w], 16-bit (a wave-round holds at most 1024).
-// The bucket of a k-mer is its first `bbits` bits (bbits <= 2(k-1), bbits <= 10), i.e. buckets are key ranges:
-// concatenating sorted buckets gives a sorted segment.  A tile is `tr` groups of GASM_WG/g reads x `orr` offset rounds;
-// round q = t * orr + o handles read group t, k-mer starts o*g*KT + lane*KT + [0, KT).  k_bucket_scatter walks the tile
-// in exactly the same order, so it needs no counting of its own.
+// The words thread `tid` needs in tile `ti`, and how many of its KT starts are k-mers.
 template <class K>
-__global__ void __launch_bounds__(GASM_WG) k_tile_hist(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles,
-                                                       u16* __restrict__ cube) {
+__device__ __forceinline__ void tile_fetch(const ReadSet& rs, const TileInfo& ti, u32 g, int k, Roll<K>& r, u32& nv) {
     constexpr u32 KT = KeyTraits<K>::KT;
-    extern __shared__ u32 s_h[];   // [rt][4][nb]
-    const u32 nb = 1u << bbits, ipt = GASM_WG / g, rt = tr * orr, rt4 = rt * 4;
-    const u32 item = threadIdx.x / g, lane = threadIdx.x % g, wv = threadIdx.x >> 6;
+    const u32 item = threadIdx.x / g, lane = threadIdx.x % g;
+    u64 p0 = 0;
+    u32 nk = 0;
+    if (item < ti.nitems) {
+        u32 len;
+        read_span(rs, ti.r0 + item, &p0, &len);
+        nk = len >= (u32)k ? len - k + 1 : 0;
+    }
+    const u32 off0 = ti.o * g * KT + lane * KT;
+    nv = off0 < nk ? min(nk - off0, KT) : 0u;
+    r.load(rs.words, nv ? p0 + off0 : 0);
+}
+
+// Bucket counts of every tile: tcnt[tile * nb + b] = k-mers of the tile whose first `bbits` bits are b (16-bit: a tile
+// holds at most GASM_TILE_WG * KT <= 8192).  Buckets are key ranges (bbits <= 2(k-1), bbits <= 10): concatenating
+// sorted buckets gives a sorted segment.
+template <class K>
+__global__ void __launch_bounds__(GASM_TILE_WG) k_tile_hist(ReadSet rs, const uint4* __restrict__ tinfo, int k, int bbits, u32 g, u32 n_tiles,
+                                                            u16* __restrict__ tcnt) {
+    constexpr u32 KT = KeyTraits<K>::KT;
+    extern __shared__ u32 s_h[];   // [nb]
+    const u32 nb = 1u << bbits;
+    for (u32 e = threadIdx.x; e < nb; e += GASM_TILE_WG) s_h[e] = 0;
+    __syncthreads();
     for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        for (u32 e = threadIdx.x; e < rt4 * nb; e += GASM_WG) s_h[e] = 0;
-        __syncthreads();
-        const TileInfo ti = tile_decode(rs, tile, ipt * tr);
-        for (u32 t = 0; t < tr; ++t) {
-            const u32 it = t * ipt + item;
-            if (it >= ti.nitems) break;
-            u64 p0; u32 len;
-            read_span(rs, ti.r0 + it, &p0, &len);
-            const u32 nk = len >= (u32)k ? len - k + 1 : 0;
-            for (u32 o = 0; o < orr; ++o) {
-                const u32 off0 = o * g * KT + lane * KT;
-                if (off0 >= nk) break;
-                Roll<K> r;
-                r.load(rs.words, p0 + off0);
-                u32* row = s_h + ((t * orr + o) * 4 + wv) * nb;
+        const TileInfo ti = tile_decode(tinfo, tile);
+        Roll<K> r;
+        u32 nv;
+        tile_fetch<K>(rs, ti, g, k, r, nv);
 #pragma unroll
-                for (u32 j = 0; j < KT; ++j) {
-                    if (off0 + j < nk) {
-                        const u32 bkt = bbits ? (u32)(r.top(j) >> (64 - bbits)) : 0u;
-                        atomicAdd(&row[bkt], 1u);
-                    }
-                }
+        for (u32 j = 0; j < KT; ++j) {
+            if (j < nv) {
+                const u32 bkt = bbits ? (u32)(r.top(j) >> (64 - bbits)) : 0u;
+                atomicAdd(&s_h[bkt], 1u);
             }
         }
         __syncthreads();
-        u16* dst = cube + (u64)tile * nb * rt4;
-        for (u32 e = threadIdx.x; e < rt4 * nb; e += GASM_WG) {
-            const u32 b = e / rt4, qw = e - b * rt4;
-            dst[e] = (u16)s_h[qw * nb + b];
-        }
+        for (u32 e = threadIdx.x; e < nb; e += GASM_TILE_WG) { tcnt[(u64)tile * nb + e] = (u16)s_h[e]; s_h[e] = 0; }
         __syncthreads();
     }
 }
-template __global__ void k_tile_hist<u64>(ReadSet, int, int, u32, u32, u32, u32, u16*);
-template __global__ void k_tile_hist<K128>(ReadSet, int, int, u32, u32, u32, u32, u16*);
+template __global__ void k_tile_hist<u64>(ReadSet, const uint4*, int, int, u32, u32, u16*);
+template __global__ void k_tile_hist<K128>(ReadSet, const uint4*, int, int, u32, u32, u16*);
 
-// Per segment and bucket: tile totals from the cube, their running sum toff[tile * nb + b] (offset of the tile inside
-// its (segment,bucket) range) and the bucket total hist[seg * nb + b].  One workgroup per segment, thread = bucket.
-// Each tile's run is rounded up to 16 k-mers = one 128-byte line, so no cache line is shared by two workgroups: partial
-// line writes from different L2s cost more than half the store bandwidth (measured: 2.1 vs 5.9 TB/s).
-__global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 rt4, const u16* __restrict__ cube,
+// Per segment and bucket: the running sum toff[tile * nb + b] of the tiles' padded counts (offset of the tile's run
+// inside its (segment,bucket) range) and the bucket total hist[seg * nb + b].  One workgroup per segment, thread =
+// bucket.  Each (tile, bucket) run is rounded up to padm + 1 keys — one 128-byte line when the bucket count allows —
+// so that no cache line is written by two workgroups: partial-line writes cost more than half the store bandwidth.
+__global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 padm, const u16* __restrict__ tcnt,
                                                     u32* __restrict__ toff, u32* __restrict__ hist) {
     const u32 nb = 1u << bbits, seg = blockIdx.x;
     const u32 t0 = rs.seg_tile_start[seg], t1 = rs.seg_tile_start[seg + 1];
     for (u32 b = threadIdx.x; b < nb; b += blockDim.x) {
         u32 run = 0;
         for (u32 t = t0; t < t1; ++t) {
-            const u16* c = cube + ((u64)t * nb + b) * rt4;
-            u32 tot = 0;
-            if ((rt4 & 7) == 0) {
-                for (u32 e = 0; e < rt4; e += 8) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(c + e);
-                    tot += (v.x & 0xFFFF) + (v.x >> 16) + (v.y & 0xFFFF) + (v.y >> 16) + (v.z & 0xFFFF) + (v.z >> 16) + (v.w & 0xFFFF) + (v.w >> 16);
-                }
-            } else {
-                for (u32 e = 0; e < rt4; ++e) tot += c[e];
-            }
             toff[(u64)t * nb + b] = run;
-            run += (tot + 15u) & ~15u;      // every (tile, bucket) run starts on a 128-byte line (filler: see k_bucket_scatter)
+            run += ((u32)tcnt[(u64)t * nb + b] + padm) & ~padm;
         }
         hist[(u64)seg * nb + b] = run;
     }
@@ -174,205 +164,143 @@ __global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, 
 template __global__ void k_scan_excl<u64>(const u32*, u64*, u32);
 template __global__ void k_scan_excl<u32>(const u32*, u32*, u32);
 
-__global__ void k_copy_u64(const u64* __restrict__ a, u64* __restrict__ b, u32 n) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) b[i] = a[i];
-}
-
 // ================================================================================================================
-// Scatter: every k-mer of every read is written once, 8 bytes, into its (segment,bucket) range of `keys`.
-// Where a wave's k-mers of one round go is fully determined beforehand: bstart[seg,bucket] + toff[tile,bucket]
-// (k_tile_scan) + the cube counts of the earlier rounds and the lower waves (k_tile_hist).  So there is no global
-// atomic, no counting pass and no workgroup barrier: each wave ranks its 1024 k-mers of a round into wave-private LDS
-// bins (one ds_add_rtn per k-mer on a cursor that starts at the bin's staging offset), then streams the staged keys
-// out bucket by bucket — the global stores of one bucket are consecutive — looking up one combined 64-bit base per key.
-// The output layout is deterministic.  LDS per wave: 1024 keys (8 KB) + nb * 12 + 8.
+// Scatter the k-mers of every tile into their (segment, bucket) ranges — whole cache lines only.
+//
+// The workgroup (512 threads = 8 waves) stages one tile in LDS, bucket by bucket: the buckets' staging ranges are
+// the exclusive scan of the tile's padded counts (k_tile_hist), a k-mer's slot inside its range comes from an LDS
+// atomic on the bucket's cursor, and the padding slots hold filler keys (top bit set + the bucket's prefix; the
+// de-duplication skips them).  Staging index i then maps to global index comb[bucket] + i, and because staging ranges
+// and global runs are both multiples of a line, 16 consecutive lanes (8 for 128-bit keys) write exactly one aligned
+// 128-byte line.  Measured on MI355X: runs that start at arbitrary 16-byte offsets reach ~3 TB/s, aligned lines
+// ~5.9 TB/s — with the stores pointed at an L2-resident scratch area the kernel ran in 0.24 ms instead of 0.57 ms, so
+// it is the write pattern at the memory side, not the CU side, that sets the time.
+//
+// Memory operations of a wave retire in order (one counter, vmcnt, for loads and stores).  A load issued after the
+// flush would therefore wait for all of the flush's stores.  So the next tile's inputs (bucket counts, bases, read
+// words) are requested BEFORE the flush, and the flush issues exactly NFL stores per thread whatever the tile holds
+// (lanes past the end write to a per-wave scratch line): the wait at the top of the next tile is then "all but the
+// last NFL operations", written out explicitly.
+// LDS: NFL * 512 keys (72 KB) + nb * 12 + 64 -> two workgroups per CU.
 // ================================================================================================================
-__device__ __forceinline__ void wave_sync_lds() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// makes the compiler wait for pending loads of these registers at this point
-__device__ __forceinline__ void touch_regs(u32 a, u32 b, u32 c, u32 d, u32 e, u32 f, u32 g, u32 h, u32 i, u32 j) {
-    __asm__ volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h), "v"(i), "v"(j));
-}
+template <class K> struct TilePrefetch {
+    Roll<K> rl;
+    u32 nv, cnt, toff, bs_lo, bs_hi;      // (the sum bstart + toff is formed after the wait, not when they are requested)
+    // explicit wait: everything requested at least N vector-memory operations ago has arrived
+    template <int N> __device__ __forceinline__ void wait_all_but() {
+        rl.template wait_all_but<N>();
+        __asm__ volatile("" : "+v"(cnt), "+v"(toff), "+v"(bs_lo), "+v"(bs_hi));     // ordered behind the wait above ("memory")
+    }
+};
 
 template <class K>
-__global__ void __launch_bounds__(GASM_WG, 4) k_bucket_scatter(ReadSet rs, int k, int bbits, u32 g, u32 tr, u32 orr, u32 n_tiles,
-                                                            const u64* __restrict__ bstart, const u32* __restrict__ toff,
-                                                            const u16* __restrict__ cube, K* __restrict__ keys, u64 scratch,
-                                                            unsigned long long* __restrict__ stamps) {
+__global__ void __launch_bounds__(GASM_TILE_WG, 2) k_bucket_scatter(ReadSet rs, const uint4* __restrict__ tinfo, int k, int bbits, u32 g, u32 padm,
+                                                                  u32 n_tiles, const u64* __restrict__ bstart, const u32* __restrict__ toff,
+                                                                  const u16* __restrict__ tcnt, K* __restrict__ keys, u64 scratch) {
     extern __shared__ __align__(16) unsigned char s_raw[];
-    // diagnostic build only (-DGASM_SCATTER_STAMPS): shader-clock totals of wave 0 per phase, summed over workgroups.
-    // Compiled out otherwise — the accumulators cost 14 registers, and the kernel sits right at 128.
-#ifdef GASM_SCATTER_STAMPS
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-    auto phase = [&](int i) {
-        if (stamps) { const unsigned long long t = __builtin_amdgcn_s_memtime(); tacc[i] += t - tlast; tlast = t; }
-    };
-#else
-    auto phase = [](int) {};
-#endif
     constexpr u32 KT = KeyTraits<K>::KT;
-    constexpr u32 WSTAGE = KT * 64;
-    const u32 rt = tr * orr, rt4 = rt * 4;
-    const u32 nb = 1u << bbits, ipt = GASM_WG / g;
-    const u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    K* s_key = reinterpret_cast<K*>(s_raw) + wv * WSTAGE;                                                   // 4 * WSTAGE
-    u64* s_comb = reinterpret_cast<u64*>(reinterpret_cast<K*>(s_raw) + 4 * WSTAGE) + wv * nb;               // 4 * nb
-    u32* s_cur = reinterpret_cast<u32*>(reinterpret_cast<u64*>(reinterpret_cast<K*>(s_raw) + 4 * WSTAGE) + 4 * nb) + wv * (nb + 2);   // 4 * (nb + 2): + dummy bin
-    const u32 item = threadIdx.x / g, lane = threadIdx.x % g;
+    constexpr u32 NFL = KeyTraits<K>::NFL;               // flush passes: KT + room for the padding
+    constexpr u32 CAP = NFL * GASM_TILE_WG;
+    const u32 nb = 1u << bbits;
+    const u32 tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    K* s_key = reinterpret_cast<K*>(s_raw);                                  // CAP
+    u64* s_comb = reinterpret_cast<u64*>(s_key + CAP);                       // nb
+    u32* s_cur = reinterpret_cast<u32*>(s_comb + nb);                        // nb + 2 (dummy bin)
+    u32* s_tmp = s_cur + nb + 2;                                             // 12
     const int bshift = 2 * k - bbits;
-    const bool fast = rt4 == 16 && nb <= 64;     // one bucket per lane, the bucket's 16 counts live in registers
+    const bool one = nb <= GASM_TILE_WG;                                     // one bucket per thread, prefetched
 
     // a workgroup takes a contiguous range of tiles (neighbouring runs of a bucket then come from the same L2)
     const u32 per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
     const u32 tile_end = min(n_tiles, (blockIdx.x + 1) * per_wg);
-    for (u32 tile = blockIdx.x * per_wg; tile < tile_end; ++tile) {
-        const TileInfo ti = tile_decode(rs, tile, ipt * tr);
-        u32 cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        u64 tbase = 0;
-        if (fast && ln < nb) {
-            const uint4* c4 = reinterpret_cast<const uint4*>(cube + ((u64)tile * nb + ln) * 16);
-            const uint4 v0 = c4[0], v1 = c4[1];
-            cw[0] = v0.x; cw[1] = v0.y; cw[2] = v0.z; cw[3] = v0.w; cw[4] = v1.x; cw[5] = v1.y; cw[6] = v1.z; cw[7] = v1.w;
-            tbase = bstart[(u64)ti.seg * nb + ln] + toff[(u64)tile * nb + ln];
+    u32 tile = blockIdx.x * per_wg;
+    if (tile >= tile_end) return;
+    const u64 my_scratch = scratch + (u64)(((blockIdx.x & 1023u) * (GASM_TILE_WG / 64) + wv) * 64 + ln);
+
+    auto fetch = [&](u32 t, const TileInfo& ti, TilePrefetch<K>& pf) {
+        pf.cnt = 0; pf.toff = 0; pf.bs_lo = 0; pf.bs_hi = 0;
+        if (one && tid < nb) {
+            pf.cnt = tcnt[(u64)t * nb + tid];
+            pf.toff = toff[(u64)t * nb + tid];
+            const uint2 b = reinterpret_cast<const uint2*>(bstart)[(u64)ti.seg * nb + tid];
+            pf.bs_lo = b.x; pf.bs_hi = b.y;
         }
-        // the words a thread needs in round q, and how many of its KT starts are k-mers
-        auto fetch_round = [&](u32 q, Roll<K>& r, u32& nv) {
-            const u32 t = q / orr, o = q - t * orr;
-            const u32 it = t * ipt + item;
-            u64 p0 = 0; u32 nk = 0;
-            if (it < ti.nitems) {
-                u32 len;
-                read_span(rs, ti.r0 + it, &p0, &len);
-                nk = len >= (u32)k ? len - k + 1 : 0;
+        tile_fetch<K>(rs, ti, g, k, pf.rl, pf.nv);
+    };
+    TileInfo ti = tile_decode(tinfo, tile);
+    TilePrefetch<K> pf;
+    fetch(tile, ti, pf);
+    pf.template wait_all_but<0>();
+    for (;;) {
+        // ---- staging ranges of the buckets
+        u32 total;
+        if (one) {
+            const u32 cnt = pf.cnt, padc = (cnt + padm) & ~padm;
+            const u32 soff = block_excl_scan<GASM_TILE_WG>(padc, s_tmp, &total);
+            if (tid < nb) {
+                s_cur[tid] = soff;
+                s_comb[tid] = (((u64)pf.bs_hi << 32) | pf.bs_lo) + pf.toff - soff;   // global index = s_comb[bucket] + staging index
+                for (u32 i = cnt; i < padc; ++i) s_key[soff + i] = key_filler<K>(tid, bshift);
             }
-            const u32 off0 = o * g * KT + lane * KT;
-            nv = off0 < nk ? min(nk - off0, KT) : 0u;
-            r.load(rs.words, nv ? p0 + off0 : 0);
-        };
-        Roll<K> rl;
-        u32 nv;
-        fetch_round(0, rl, nv);
-        // Every load so far is waited for here, once, outside the round loop: a wait placed inside the loop would also
-        // cover the loop's own stores (see the note at the prefetch below).
-        touch_regs(cw[0], cw[1], cw[2], cw[3], cw[4], cw[5], cw[6], cw[7], (u32)tbase, (u32)(tbase >> 32));
-        rl.touch();
-        // filler behind the tile's run of every bucket, up to the next 128-byte line (the de-duplication skips it)
-        if (wv == 0) {
-            for (u32 b = ln; b < nb; b += 64) {
-                u32 tot = 0;
-                u64 base;
-                if (fast) {
+        } else {
+            u32 carry = 0;
+            for (u32 b0 = 0; b0 < nb; b0 += GASM_TILE_WG) {
+                const u32 b = b0 + tid;
+                const u32 cnt = tcnt[(u64)tile * nb + b], padc = (cnt + padm) & ~padm;
+                u32 tot;
+                const u32 soff = carry + block_excl_scan<GASM_TILE_WG>(padc, s_tmp, &tot);
+                s_cur[b] = soff;
+                s_comb[b] = bstart[(u64)ti.seg * nb + b] + toff[(u64)tile * nb + b] - soff;
+                for (u32 i = cnt; i < padc; ++i) s_key[soff + i] = key_filler<K>(b, bshift);
+                carry += tot;
+            }
+            total = carry;
+        }
+        __syncthreads();
+        // ---- rank and stage.  The ds_add_rtn of a thread are issued back to back (a start past the end of the read
+        // ranks into a dummy bin) and waited for once; a branch per k-mer would make them dependent LDS round trips.
+        const Roll<K> rl = pf.rl;
+        const u32 nv = pf.nv;
+        K key[KT];
+        u32 idx[KT];
 #pragma unroll
-                    for (u32 e = 0; e < 8; ++e) tot += (cw[e] & 0xFFFF) + (cw[e] >> 16);
-                    base = tbase;
-                } else {
-                    const u16* c = cube + ((u64)tile * nb + b) * rt4;
-                    for (u32 e = 0; e < rt4; ++e) tot += c[e];
-                    base = bstart[(u64)ti.seg * nb + b] + toff[(u64)tile * nb + b];
-                }
-                for (u32 i = tot; i < ((tot + 15u) & ~15u); ++i) keys[base + i] = key_empty<K>();
+        for (u32 j = 0; j < KT; ++j) {
+            key[j] = rl.key(j, k);
+            const u32 bkt = bbits ? (u32)(rl.top(j) >> (64 - bbits)) : 0u;
+            idx[j] = atomicAdd(&s_cur[j < nv ? bkt : nb], 1u);
+        }
+        // ---- the next tile's inputs, requested ahead of this tile's stores (the last tile re-requests its own)
+        const u32 tnext = tile + 1 < tile_end ? tile + 1 : tile;
+        const TileInfo tin = tile_decode(tinfo, tnext);
+        fetch(tnext, tin, pf);
+#pragma unroll
+        for (u32 j = 0; j < KT; ++j)
+            if (j < nv) s_key[idx[j]] = key[j];
+        __syncthreads();
+        // ---- stream out: NFL stores per thread, three keys at a time (their LDS reads overlap)
+        static_assert(NFL % 3 == 0, "flush passes come in threes");
+#pragma unroll
+        for (u32 u0 = 0; u0 < NFL; u0 += 3) {
+            K kk[3];
+            u64 cb[3];
+#pragma unroll
+            for (u32 u = 0; u < 3; ++u) kk[u] = s_key[tid + GASM_TILE_WG * (u0 + u)];
+#pragma unroll
+            for (u32 u = 0; u < 3; ++u) cb[u] = s_comb[bbits ? (kfield(kk[u], bshift) & (nb - 1)) : 0u];
+#pragma unroll
+            for (u32 u = 0; u < 3; ++u) {
+                const u32 i = tid + GASM_TILE_WG * (u0 + u);
+                keys[i < total ? cb[u] + i : my_scratch] = kk[u];
             }
         }
-        u32 run_before = 0;   // fast path: k-mers of this lane's bucket in earlier rounds (all waves)
-        phase(0);
-        for (u32 q = 0; q < rt; ++q) {
-            // ---- where this wave's k-mers of round q go, bucket by bucket
-            u32 kcar = 0;
-            for (u32 b0 = 0; b0 < nb; b0 += 64) {
-                const u32 b = b0 + ln;
-                u32 own = 0;
-                u64 base = 0;
-                if (fast) {
-                    // counts of round q: words 2q, 2q+1 = waves (0,1), (2,3)
-                    u32 w01 = 0, w23 = 0;
-#pragma unroll
-                    for (u32 e = 0; e < 4; ++e) if (e == q) { w01 = cw[2 * e]; w23 = cw[2 * e + 1]; }
-                    const u32 c0 = w01 & 0xFFFF, c1 = w01 >> 16, c2 = w23 & 0xFFFF, c3 = w23 >> 16;
-                    own = wv == 0 ? c0 : wv == 1 ? c1 : wv == 2 ? c2 : c3;
-                    const u32 lower = (wv > 0 ? c0 : 0) + (wv > 1 ? c1 : 0) + (wv > 2 ? c2 : 0);
-                    base = tbase + run_before + lower;
-                    run_before += c0 + c1 + c2 + c3;
-                } else if (b < nb) {
-                    const u16* c = cube + ((u64)tile * nb + b) * rt4;
-                    u32 before = 0;
-                    for (u32 e = 0; e < q * 4 + wv; ++e) before += c[e];    // earlier rounds, and lower waves of this one
-                    own = c[q * 4 + wv];
-                    base = bstart[(u64)ti.seg * nb + b] + toff[(u64)tile * nb + b] + before;
-                }
-                const u32 inc = wave_incl_scan(own);
-                const u32 off = kcar + inc - own;                    // staging offset of the bin
-                if (b < nb) {
-                    s_cur[b] = off;
-                    s_comb[b] = base - off;                          // global index = s_comb[bucket] + staging index
-                }
-                kcar += wave_last(inc);
-            }
-            const u32 staged = kcar;
-            wave_sync_lds();
-            phase(1);
-            // ---- rank and stage.  The ds_add_rtn of a thread are issued back to back (a position past the end of the read
-            // ranks into a dummy bin) and waited for once; a branch per k-mer would make them dependent LDS round trips.
-            // the words of this round were requested before the previous round's KT stores (first round: already waited for)
-            rl.template wait_all_but<KT>();
-            K key[KT];
-            u32 idx[KT];
-#ifdef GASM_SCATTER_STAMPS
-            if (stamps) { key[0] = rl.key(0, k); if (kis_empty(key[0])) tacc[5] += 1; phase(2); }   // words have arrived
-#endif
-#pragma unroll
-            for (u32 j = 0; j < KT; ++j) {
-                key[j] = rl.key(j, k);
-                const u32 bkt = bbits ? (u32)(rl.top(j) >> (64 - bbits)) : 0u;
-                idx[j] = atomicAdd(&s_cur[j < nv ? bkt : nb], 1u);
-            }
-            // The next round's words are requested now, ahead of this round's stores: memory operations of a wave
-            // retire in order (one counter for loads and stores), so a load issued after the stores would wait for all
-            // of them.  The flush below issues exactly KT stores whatever `staged` is — the wait for these words can
-            // then be "all but the last KT operations" instead of "everything".
-            Roll<K> rn;
-            u32 nvn;
-            fetch_round(min(q + 1, rt - 1), rn, nvn);
-#ifdef GASM_SCATTER_STAMPS
-            if (stamps) { if (idx[KT - 1] == 0xFFFFFFFFu) tacc[5] += 1; phase(3); }                  // atomics have returned
-#endif
-#pragma unroll
-            for (u32 j = 0; j < KT; ++j)
-                if (j < nv) s_key[idx[j]] = key[j];
-            wave_sync_lds();
-            phase(4);
-            // ---- stream out, four keys per thread at a time (their LDS reads overlap); lanes past the end store to a
-            // scratch line behind the key array instead of branching
-#pragma unroll
-            for (u32 u0 = 0; u0 < KT; u0 += 4) {
-                K kk[4];
-                u64 cb[4];
-#pragma unroll
-                for (u32 u = 0; u < 4; ++u) kk[u] = s_key[ln + 64 * (u0 + u)];
-#pragma unroll
-                for (u32 u = 0; u < 4; ++u) cb[u] = s_comb[bbits ? (kfield(kk[u], bshift) & (nb - 1)) : 0u];
-#pragma unroll
-                for (u32 u = 0; u < 4; ++u) {
-                    const u32 i = ln + 64 * (u0 + u);
-                    keys[i < staged ? cb[u] + i : scratch + ln] = kk[u];
-                }
-            }
-            wave_sync_lds();
-            phase(5);
-            rl = rn;
-            nv = nvn;
-        }
+        if (++tile >= tile_end) break;
+        __syncthreads();          // staging is free again
+        ti = tin;
+        pf.template wait_all_but<NFL>();
     }
-#ifdef GASM_SCATTER_STAMPS
-    if (stamps && threadIdx.x == 0)
-        for (int i = 0; i < 6; ++i) atomicAdd(&stamps[i], tacc[i]);
-#endif
 }
-template __global__ void k_bucket_scatter<u64>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, const u16*, u64*, u64, unsigned long long*);
-template __global__ void k_bucket_scatter<K128>(ReadSet, int, int, u32, u32, u32, u32, const u64*, const u32*, const u16*, K128*, u64, unsigned long long*);
+template __global__ void k_bucket_scatter<u64>(ReadSet, const uint4*, int, int, u32, u32, u32, const u64*, const u32*, const u16*, u64*, u64);
+template __global__ void k_bucket_scatter<K128>(ReadSet, const uint4*, int, int, u32, u32, u32, const u64*, const u32*, const u16*, K128*, u64);
 
 // ================================================================================================================
 // De-duplicate one bucket: stream its keys through an LDS table (count per distinct key), then order the distinct keys
@@ -519,7 +447,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const u64 key = kx[4 * h + q];
-                    if (key == GASM_EMPTY64) continue;
+                    if (kis_filler(key)) continue;
                     const int slot = c01[q].x == key ? 0 : c01[q].y == key ? 1 : c23[q].x == key ? 2 : c23[q].y == key ? 3 : -1;
                     if (slot >= 0) atomicAdd(&t_cnt[4 * set[q] + slot], 1u);
                     else {
@@ -546,7 +474,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const K128 key = kx[q];
-                if (kis_empty(key)) continue;
+                if (kis_filler(key)) continue;
                 const bool r0 = cn[q].x != 0 && cn[q].x != GASM_SLOT_LOCKED, r1 = cn[q].y != 0 && cn[q].y != GASM_SLOT_LOCKED;
                 if (r0 && k0[q].x == key.hi && k0[q].y == key.lo) atomicAdd(&t_cnt[4 * set[q]], 1u);
                 else if (r0 && r1 && k1[q].x == key.hi && k1[q].y == key.lo) atomicAdd(&t_cnt[4 * set[q] + 1], 1u);

@@ -16,6 +16,10 @@ template <class K> __device__ __forceinline__ K key_from_u64(u64 v);
 template <> __device__ __forceinline__ u64 key_from_u64<u64>(u64 v) { return v; }
 template <> __device__ __forceinline__ K128 key_from_u64<K128>(u64 v) { return K128{0, v}; }
 
+// filler keys of the bucketed key array: top bit set (no k-mer has it: 2k <= 62 resp. 126 bits) over the bucket prefix
+template <class K> __device__ __forceinline__ K key_filler(u32 bkt, int bshift);
+__device__ __forceinline__ bool kis_filler(u64 a) { return (a >> 63) != 0; }
+
 // ---- comparisons
 __device__ __forceinline__ bool keq(u64 a, u64 b) { return a == b; }
 __device__ __forceinline__ bool keq(const K128& a, const K128& b) { return a.hi == b.hi && a.lo == b.lo; }
@@ -23,6 +27,8 @@ __device__ __forceinline__ bool kless(u64 a, u64 b) { return a < b; }
 __device__ __forceinline__ bool kless(const K128& a, const K128& b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
 __device__ __forceinline__ bool kis_empty(u64 a) { return a == GASM_EMPTY64; }
 __device__ __forceinline__ bool kis_empty(const K128& a) { return (a.hi & a.lo) == GASM_EMPTY64; }
+
+__device__ __forceinline__ bool kis_filler(const K128& a) { return (a.hi >> 63) != 0; }
 
 // ---- shifts (0 <= s < width) and bit operations
 __device__ __forceinline__ u64 kshr(u64 a, int s) { return a >> s; }
@@ -45,6 +51,11 @@ __device__ __forceinline__ K128 klowbits(const K128& a, int bits) {
     if (bits >= 128) return a;
     if (bits >= 64) return K128{bits == 64 ? 0 : (a.hi & ((1ull << (bits - 64)) - 1)), a.lo};
     return K128{0, a.lo & ((1ull << bits) - 1)};
+}
+template <> __device__ __forceinline__ u64 key_filler<u64>(u32 bkt, int bshift) { return (1ull << 63) | ((u64)bkt << bshift); }
+template <> __device__ __forceinline__ K128 key_filler<K128>(u32 bkt, int bshift) {
+    const K128 b = kshl(K128{0, (u64)bkt}, bshift);
+    return K128{b.hi | (1ull << 63), b.lo};
 }
 // low 32 bits of (a >> s)
 __device__ __forceinline__ u32 kfield(u64 a, int s) { return (u32)(a >> s); }
@@ -123,5 +134,6 @@ template <> struct Roll<K128> {
 
 // words per key and k-mers per thread and round of the tile kernels (LDS staging is 8 KB per wave either way)
 template <class K> struct KeyTraits;
-template <> struct KeyTraits<u64> { static constexpr int WORDS = 1; static constexpr int KT = 16; };
-template <> struct KeyTraits<K128> { static constexpr int WORDS = 2; static constexpr int KT = 8; };
+// NFL: store passes of k_bucket_scatter's flush = KT + room for the padding of the staged runs (72 KB of LDS either way)
+template <> struct KeyTraits<u64> { static constexpr int WORDS = 1; static constexpr int KT = 16; static constexpr int NFL = 18; };
+template <> struct KeyTraits<K128> { static constexpr int WORDS = 2; static constexpr int KT = 8; static constexpr int NFL = 9; };

@@ -15,13 +15,13 @@ struct DevReads {
     std::vector<u64> h_seg_empty;           // empty reads per segment
     DBuf d_words, d_read_off, d_seg_read_off;
     // tile directory cache (depends on reads per tile)
-    u32 tiles_ipt = 0, n_tiles = 0;
+    u32 tiles_ipt = 0, tiles_orr = 0, n_tiles = 0;
     std::vector<u32> h_seg_tile_start, h_tile_info;
     DBuf d_seg_tile_start, d_tile_info;
 
     int upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off,
                u32 n_segments);
-    int set_tiles(gasm_ctx* ctx, u32 ipt);
+    int set_tiles(gasm_ctx* ctx, u32 ipt, u32 orr);
     ReadSet view() const;
     u64 read_len(u64 r) const { return fixed_len ? fixed_len : h_read_off[r + 1] - h_read_off[r]; }
     void release();

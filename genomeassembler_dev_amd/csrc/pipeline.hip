@@ -107,13 +107,14 @@ int DevReads::upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 
     return GASM_OK;
 }
 
-int DevReads::set_tiles(gasm_ctx* ctx, u32 ipt) {
-    if (tiles_ipt == ipt) return GASM_OK;
+// Tile table: a tile = up to ipt consecutive reads of one segment at one of orr offset rounds (kernels_build.hip, "Tiles").
+int DevReads::set_tiles(gasm_ctx* ctx, u32 ipt, u32 orr) {
+    if (tiles_ipt == ipt && tiles_orr == orr) return GASM_OK;
     std::vector<u32>& t = h_seg_tile_start;
     t.assign(n_segments + 1, 0);
     for (u32 s = 0; s < n_segments; ++s) {
         const u64 rs = h_seg_read_off[s + 1] - h_seg_read_off[s];
-        const u64 nt = (rs + ipt - 1) / ipt;
+        const u64 nt = (rs + ipt - 1) / ipt * orr;
         if ((u64)t[s] + nt > 0xFFFFFFF0ull) { gasm_set_error("too many tiles"); return GASM_ERR_CAPACITY; }
         t[s + 1] = t[s] + (u32)nt;
     }
@@ -123,13 +124,16 @@ int DevReads::set_tiles(gasm_ctx* ctx, u32 ipt) {
     info.assign((size_t)n_tiles * 4 + 4, 0);
     for (u32 s = 0; s < n_segments; ++s)
         for (u32 tile = t[s]; tile < t[s + 1]; ++tile) {
-            const u64 first = h_seg_read_off[s] + (u64)(tile - t[s]) * ipt;
+            const u32 grp = (tile - t[s]) / orr, o = (tile - t[s]) % orr;
+            const u64 first = h_seg_read_off[s] + (u64)grp * ipt;
             const u64 left = h_seg_read_off[s + 1] - first;
+            if ((first >> 48) != 0) { gasm_set_error("too many reads"); return GASM_ERR_CAPACITY; }
             u32* e = &info[(size_t)tile * 4];
-            e[0] = s; e[1] = (u32)std::min<u64>(left, ipt); e[2] = (u32)first; e[3] = (u32)(first >> 32);
+            e[0] = s; e[1] = (u32)std::min<u64>(left, ipt); e[2] = (u32)first; e[3] = (u32)(first >> 32) | (o << 16);
         }
     GCHK(h2d(ctx, d_tile_info, info.data(), info.size() * 4));
     tiles_ipt = ipt;
+    tiles_orr = orr;
     return GASM_OK;
 }
 
@@ -247,14 +251,13 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     }
     bs.n_kmers = N;
     const u32 nk_max = rd.max_len >= (u32)k ? rd.max_len - k + 1 : 0;
-    u32 g = next_pow2_u32((nk_max + KT - 1) / KT);
-    g = std::max(1u, std::min(64u, g));
-    const u32 ipt = GASM_WG / g;
-    // a scatter tile = tr read groups x orr offset rounds (orr > 1 only for reads longer than g*KT k-mers)
+    u32 g = next_pow2_u32((nk_max + KT - 1) / KT);     // threads per read (a power of two: divides the workgroup)
+    g = std::max(1u, std::min((u32)GASM_TILE_WG, g));
+    const u32 ipt = GASM_TILE_WG / g;
+    // offset rounds: more than one only for reads with more than g*KT k-mers; every (read group, round) is a tile
     const u32 orr = std::max(1u, (nk_max + g * KT - 1) / (g * KT));
-    if (orr > GASM_RT_MAX) { gasm_set_error("reads longer than %u bases are not supported", 64u * KT * GASM_RT_MAX); return GASM_ERR_CAPACITY; }
-    const u32 tr = orr == 1 ? 4u : 1u;
-    GCHK(rd.set_tiles(ctx, ipt * tr));
+    if (orr > 0xFFFFu) { gasm_set_error("reads longer than %u bases are not supported", GASM_TILE_WG * KT * 0xFFFFu); return GASM_ERR_CAPACITY; }
+    GCHK(rd.set_tiles(ctx, ipt, orr));
     // bucket bits: aim at <= ~900 distinct k-mers per bucket (2048-slot LDS table in 4-slot sets, limit 1408)
     const int bb_cap = std::min(10, 2 * (k - 1));
     int bbits = 0;
@@ -290,63 +293,47 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         HIPCHK(hipStreamSynchronize(ctx->stream));
         return GASM_OK;
     }
-    // every (tile, bucket) run is padded to a multiple of 16 keys: room for the filler (bucket count fixed below)
-    const u64 n_pad_max = N + 16ull * rd.n_tiles * (1ull << bb_cap);
+    // every (tile, bucket) run is padded to a multiple of padm + 1 keys (a 128-byte line when the bucket count allows;
+    // the padding of one tile must fit the flush passes k_bucket_scatter has beyond KT)
+    const u32 line_keys = 128 / KB, pad_room = W == 1 ? 2 * GASM_TILE_WG : GASM_TILE_WG;
+    auto pad_mask = [&](u32 nb) { u32 m = line_keys - 1; while (m && (u64)nb * m > pad_room) m >>= 1; return m; };
     const ReadSet rs = rd.view();
-    const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * 16);
+    const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * 8);
+    constexpr u32 SCRATCH_KEYS = 1024 * (GASM_TILE_WG / 64) * 64;   // a line-set per wave of 1024 workgroup slots (k_bucket_scatter)
     u32 nbt = 0;
     while (true) {
-        const u32 nb = 1u << bbits;
+        const u32 nb = 1u << bbits, padm = pad_mask(nb);
         nbt = S * nb;
         GCHK(bs.d_hist.ensure((size_t)nbt * 4));
         GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 4));
-        // (+ 64 keys of scratch behind the array: where k_bucket_scatter's idle lanes store)
-        const u64 n_alloc = std::min<u64>(n_pad_max, N + 16ull * rd.n_tiles * nb);
-        GCHK(bs.d_keys.ensure((n_alloc + 64) * KB));
+        const u64 n_alloc = N + (u64)padm * rd.n_tiles * nb;
+        GCHK(bs.d_keys.ensure((n_alloc + SCRATCH_KEYS) * KB));
         GCHK(bs.d_mult.ensure(n_alloc * 4));
-        GCHK(bs.d_cube.ensure((size_t)rd.n_tiles * nb * tr * orr * 4 * 2 + 64));
+        GCHK(bs.d_cube.ensure((size_t)rd.n_tiles * nb * 2 + 64));
         GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
         GCHK(bs.d_dstart.ensure(((size_t)nbt + 2) * 4));
         HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 64, ctx->stream));
-        const u32 rt = tr * orr;
-        if ((size_t)rt * 4 * nb * 4 > 160 * 1024) { gasm_set_error("count cube does not fit LDS"); return GASM_ERR_CAPACITY; }
         if (W == 1) {
-            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_WG), (size_t)rt * 4 * nb * 4, rs, k, bbits, g, tr, orr,
-                    rd.n_tiles, bs.d_cube.as<u16>());
+            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 4, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
+                    bs.d_cube.as<u16>());
         } else {
-            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_WG), (size_t)rt * 4 * nb * 4, rs, k, bbits, g, tr, orr,
-                    rd.n_tiles, bs.d_cube.as<u16>());
+            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 4, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
+                    bs.d_cube.as<u16>());
         }
-        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(std::min(1024u, std::max(64u, nb))), 0, rs, bbits, rt * 4, bs.d_cube.as<u16>(),
+        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(std::min(1024u, std::max(64u, nb))), 0, rs, bbits, padm, bs.d_cube.as<u16>(),
                 bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
-        size_t lds = (size_t)KT * 64 * 4 * KB + (size_t)nb * 48 + 64;
-        if (getenv("GASM_DBG_SCATTER_LDSPAD")) lds += (size_t)atoi(getenv("GASM_DBG_SCATTER_LDSPAD"));   // tuning: fewer workgroups per CU
-        const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 64));
-        unsigned long long* d_sstamps = nullptr;
-        static DBuf sstamp_buf;
-        if (getenv("GASM_DBG_SCATTER_STAMPS")) {   // diagnostic: per-phase shader-clock totals of k_bucket_scatter (wave 0 of every workgroup)
-            GCHK(sstamp_buf.ensure(64));
-            HIPCHK(hipMemsetAsync(sstamp_buf.p, 0, 64, ctx->stream));
-            d_sstamps = sstamp_buf.as<unsigned long long>();
-        }
+        const size_t lds = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (size_t)nb * 12 + 64;   // KeyTraits<K>::NFL passes
+        // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
+        const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 8));
         if (W == 1) {
-            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), n_alloc, d_sstamps);
+            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), n_alloc);
         } else {
-            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_WG), lds, rs, k, bbits, g, tr, orr, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<K128>(), n_alloc, d_sstamps);
-        }
-        if (d_sstamps) {
-            unsigned long long h[6];
-            HIPCHK(hipMemcpyAsync(h, d_sstamps, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            const double wr = (double)rd.n_tiles * tr * orr;   // wave-0 rounds in total
-            fprintf(stderr, "[scatter stamps, shader clocks per round of wave 0; %u workgroups] tile-prologue %.0f  bins %.0f  words-arrive %.0f  "
-                    "atomics %.0f  stage %.0f  flush+sync %.0f\n", grid_scatter, (double)h[0] / wr, (double)h[1] / wr, (double)h[2] / wr,
-                    (double)h[3] / wr, (double)h[4] / wr, (double)h[5] / wr);
+            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<K128>(), n_alloc);
         }
         unsigned long long* d_stamps = nullptr;
         static DBuf stamp_buf;
@@ -354,7 +341,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
             int o1 = 0, o2 = 0, o3 = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_bucket_dedup<u64, 2048>, GASM_WG, 0);
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_bucket_dedup<u64, 4096>, GASM_WG, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, k_bucket_scatter<u64>, GASM_WG, (size_t)GASM_KT * 64 * 4 * 8 + (size_t)nb * 48 + 64);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, k_bucket_scatter<u64>, GASM_TILE_WG, lds);
             fprintf(stderr, "[occupancy API] dedup<2048> %d  dedup<4096> %d  scatter %d blocks/CU\n", o1, o2, o3);
             GCHK(stamp_buf.ensure(64 + (size_t)nbt * 24));
             HIPCHK(hipMemsetAsync(stamp_buf.p, 0, 64 + (size_t)nbt * 24, ctx->stream));
