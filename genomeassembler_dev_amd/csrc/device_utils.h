@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 
 typedef uint64_t u64;
 typedef uint32_t u32;
@@ -32,6 +33,12 @@ __device__ __forceinline__ u64 kmer_at(const u64* __restrict__ w, u64 p, int k) 
 
 __device__ __forceinline__ u32 base_code(u8 c) { return ((c >> 1) & 3u) ^ ((c >> 2) & 1u); }  // A0 C1 G2 T3
 __device__ __forceinline__ bool base_ok(u8 c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+
+// f(integral_constant<u32, 0>) ... f(integral_constant<u32, N-1>): a loop whose index is a compile-time constant
+template <class F, u32... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<u32, Is...>) { (f(std::integral_constant<u32, Is>{}), ...); }
+template <u32 N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<u32, N>{}); }
 
 __device__ __forceinline__ u32 hash64(u64 x) { return (u32)((x * 0x9E3779B97F4A7C15ull) >> 32); }
 

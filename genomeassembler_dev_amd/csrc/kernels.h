@@ -67,7 +67,7 @@ struct PathSet {
 
 // ---- kernels_build.hip
 __global__ void k_pack_ascii(const u8* ascii, u64 nbases, u64* words, u64 nwords, u32* err);
-#define GASM_TILE_WG 512    // threads of a tile workgroup (k_tile_hist, k_bucket_scatter)
+#define GASM_TILE_WG 512     // threads of a tile workgroup (k_tile_hist, k_bucket_scatter)
 template <class K> __global__ void k_tile_hist(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 n_tiles, u16* tcnt);
 __global__ void k_tile_scan(ReadSet rs, int bbits, u32 padm, const u16* tcnt, u32* toff, u32* hist);
 template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);

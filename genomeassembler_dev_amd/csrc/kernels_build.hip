@@ -113,13 +113,11 @@ __global__ void __launch_bounds__(GASM_TILE_WG) k_tile_hist(ReadSet rs, const ui
         Roll<K> r;
         u32 nv;
         tile_fetch<K>(rs, ti, g, k, r, nv);
-#pragma unroll
-        for (u32 j = 0; j < KT; ++j) {
-            if (j < nv) {
-                const u32 bkt = bbits ? (u32)(r.top(j) >> (64 - bbits)) : 0u;
-                atomicAdd(&s_h[bkt], 1u);
-            }
-        }
+        const auto w = r.prep();
+        static_for<KT>([&](auto J) {
+            constexpr u32 j = J;
+            if (j < nv) atomicAdd(&s_h[bbits ? w.template top_hi<j>() >> (32 - bbits) : 0u], 1u);
+        });
         __syncthreads();
         for (u32 e = threadIdx.x; e < nb; e += GASM_TILE_WG) { tcnt[(u64)tile * nb + e] = (u16)s_h[e]; s_h[e] = 0; }
         __syncthreads();
@@ -134,15 +132,27 @@ template __global__ void k_tile_hist<K128>(ReadSet, const uint4*, int, int, u32,
 // so that no cache line is written by two workgroups: partial-line writes cost more than half the store bandwidth.
 __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 padm, const u16* __restrict__ tcnt,
                                                     u32* __restrict__ toff, u32* __restrict__ hist) {
+    __shared__ u32 s_part[1024];
     const u32 nb = 1u << bbits, seg = blockIdx.x;
     const u32 t0 = rs.seg_tile_start[seg], t1 = rs.seg_tile_start[seg + 1];
-    for (u32 b = threadIdx.x; b < nb; b += blockDim.x) {
+    // the workgroup is `grp` slices of the tile range x min(nb, 1024) buckets: slice sums first, then the offsets
+    const u32 nbw = min(nb, 1024u), grp = 1024u / nbw, sl = threadIdx.x / nbw, bl = threadIdx.x % nbw;
+    const u32 per = (t1 - t0 + grp - 1) / grp;
+    const u32 ta = min(t1, t0 + sl * per), tb = min(t1, ta + per);
+    for (u32 b0 = 0; b0 < nb; b0 += nbw) {
+        const u32 b = b0 + bl;
+        u32 sum = 0;
+        for (u32 t = ta; t < tb; ++t) sum += ((u32)tcnt[(u64)t * nb + b] + padm) & ~padm;
+        s_part[threadIdx.x] = sum;
+        __syncthreads();
         u32 run = 0;
-        for (u32 t = t0; t < t1; ++t) {
+        for (u32 s = 0; s < sl; ++s) run += s_part[s * nbw + bl];
+        if (sl == grp - 1) hist[(u64)seg * nb + b] = run + sum;
+        __syncthreads();
+        for (u32 t = ta; t < tb; ++t) {
             toff[(u64)t * nb + b] = run;
             run += ((u32)tcnt[(u64)t * nb + b] + padm) & ~padm;
         }
-        hist[(u64)seg * nb + b] = run;
     }
 }
 
@@ -194,7 +204,7 @@ template <class K> struct TilePrefetch {
 };
 
 template <class K>
-__global__ void __launch_bounds__(GASM_TILE_WG, 2) k_bucket_scatter(ReadSet rs, const uint4* __restrict__ tinfo, int k, int bbits, u32 g, u32 padm,
+__global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_scatter(ReadSet rs, const uint4* __restrict__ tinfo, int k, int bbits, u32 g, u32 padm,
                                                                   u32 n_tiles, const u64* __restrict__ bstart, const u32* __restrict__ toff,
                                                                   const u16* __restrict__ tcnt, K* __restrict__ keys, u64 scratch) {
     extern __shared__ __align__(16) unsigned char s_raw[];
@@ -203,8 +213,8 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 2) k_bucket_scatter(ReadSet rs, 
     constexpr u32 CAP = NFL * GASM_TILE_WG;
     const u32 nb = 1u << bbits;
     const u32 tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
-    K* s_key = reinterpret_cast<K*>(s_raw);                                  // CAP
-    u64* s_comb = reinterpret_cast<u64*>(s_key + CAP);                       // nb
+    K* s_key = reinterpret_cast<K*>(s_raw);                                  // CAP + one trash slot per thread
+    u64* s_comb = reinterpret_cast<u64*>(s_key + CAP + GASM_TILE_WG);        // nb
     u32* s_cur = reinterpret_cast<u32*>(s_comb + nb);                        // nb + 2 (dummy bin)
     u32* s_tmp = s_cur + nb + 2;                                             // 12
     const int bshift = 2 * k - bbits;
@@ -239,7 +249,7 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 2) k_bucket_scatter(ReadSet rs, 
             const u32 soff = block_excl_scan<GASM_TILE_WG>(padc, s_tmp, &total);
             if (tid < nb) {
                 s_cur[tid] = soff;
-                s_comb[tid] = (((u64)pf.bs_hi << 32) | pf.bs_lo) + pf.toff - soff;   // global index = s_comb[bucket] + staging index
+                s_comb[tid] = (((u64)pf.bs_hi << 32) | pf.bs_lo) + pf.toff - soff;   // staging index i goes to keys[s_comb[bucket] + i]
                 for (u32 i = cnt; i < padc; ++i) s_key[soff + i] = key_filler<K>(tid, bshift);
             }
         } else {
@@ -259,23 +269,23 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 2) k_bucket_scatter(ReadSet rs, 
         __syncthreads();
         // ---- rank and stage.  The ds_add_rtn of a thread are issued back to back (a start past the end of the read
         // ranks into a dummy bin) and waited for once; a branch per k-mer would make them dependent LDS round trips.
-        const Roll<K> rl = pf.rl;
+        const auto w = pf.rl.prep();
         const u32 nv = pf.nv;
         K key[KT];
         u32 idx[KT];
-#pragma unroll
-        for (u32 j = 0; j < KT; ++j) {
-            key[j] = rl.key(j, k);
-            const u32 bkt = bbits ? (u32)(rl.top(j) >> (64 - bbits)) : 0u;
+        static_for<KT>([&](auto J) {
+            constexpr u32 j = J;
+            key[j] = w.template key<j>(k);
+            const u32 bkt = bbits ? w.template top_hi<j>() >> (32 - bbits) : 0u;
             idx[j] = atomicAdd(&s_cur[j < nv ? bkt : nb], 1u);
-        }
+        });
         // ---- the next tile's inputs, requested ahead of this tile's stores (the last tile re-requests its own)
         const u32 tnext = tile + 1 < tile_end ? tile + 1 : tile;
         const TileInfo tin = tile_decode(tinfo, tnext);
         fetch(tnext, tin, pf);
+        // (a start past the end of the read goes to the thread's trash slot: cheaper than a branch per k-mer)
 #pragma unroll
-        for (u32 j = 0; j < KT; ++j)
-            if (j < nv) s_key[idx[j]] = key[j];
+        for (u32 j = 0; j < KT; ++j) s_key[j < nv ? idx[j] : CAP + tid] = key[j];
         __syncthreads();
         // ---- stream out: NFL stores per thread, three keys at a time (their LDS reads overlap)
         static_assert(NFL % 3 == 0, "flush passes come in threes");
@@ -290,7 +300,7 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 2) k_bucket_scatter(ReadSet rs, 
 #pragma unroll
             for (u32 u = 0; u < 3; ++u) {
                 const u32 i = tid + GASM_TILE_WG * (u0 + u);
-                keys[i < total ? cb[u] + i : my_scratch] = kk[u];
+                keys[i < total ? cb[u] + i : my_scratch] = kk[u];      // (no branch: the number of stores must not vary)
             }
         }
         if (++tile >= tile_end) break;

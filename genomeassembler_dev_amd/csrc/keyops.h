@@ -76,7 +76,16 @@ template <> __device__ __forceinline__ K128 kmer_key_at<K128>(const u64* __restr
 }
 
 // Rolling source: KT consecutive k-mer starts out of a few words held in registers (3 words cover 16 + 31 bases,
-// 4 words cover 8 + 63 + 31 bases).
+// 4 words cover 8 + 63 + 31 bases).  The raw words are what a prefetch holds; prep() aligns them once to the thread's
+// first base (a run of 32-bit words d[n-1]..d[0]), after which the window j bases further on is a pair of v_alignbit
+// with the constant shift 32 - 2j — two instructions per k-mer and no dependency between k-mers.
+__device__ __forceinline__ u64 funnel64(u64 x, u64 y, u32 o) { return (x << o) | ((y >> 1) >> (63 - o)); }   // 0 <= o < 64
+// bits [32 + 2j, 2j) ... i.e. the 32-bit word starting 2j bits into hi:lo (0 <= j <= 15)
+template <u32 J> __device__ __forceinline__ u32 word_at(u32 hi, u32 lo) {
+    if constexpr (J == 0) return hi;
+    else return __builtin_amdgcn_alignbit(hi, lo, 32 - 2 * J);
+}
+
 template <class K> struct Roll;
 template <> struct Roll<u64> {
     u64 w0, w1, w2;
@@ -86,15 +95,18 @@ template <> struct Roll<u64> {
         w0 = w[i]; w1 = w[i + 1]; w2 = w[i + 2];
         s = (u32)(p & 31) << 1;
     }
-    // the 32 bases starting j bases after the load position (0 <= j < 32): also the top of every k-mer there
-    __device__ __forceinline__ u64 top(u32 j) const {
-        const u32 ob = s + 2 * j;            // < 126
-        const bool hi = ob >= 64;
-        const u64 x = hi ? w1 : w0, y = hi ? w2 : w1;
-        const u32 o = ob & 63;
-        return (x << o) | ((y >> 1) >> (63 - o));
+    // the 96 bits (48 bases) from the load position
+    struct Win {
+        u32 d3, d2, d1;
+        // the 32 bases starting J bases after the load position (J < 16): also the top of every k-mer there
+        template <u32 J> __device__ __forceinline__ u64 top() const { return ((u64)word_at<J>(d3, d2) << 32) | word_at<J>(d2, d1); }
+        template <u32 J> __device__ __forceinline__ u32 top_hi() const { return word_at<J>(d3, d2); }
+        template <u32 J> __device__ __forceinline__ u64 key(int k) const { return top<J>() >> (64 - 2 * k); }
+    };
+    __device__ __forceinline__ Win prep() const {
+        const u64 hi = funnel64(w0, w1, s), lo = funnel64(w1, w2, s);
+        return Win{(u32)(hi >> 32), (u32)hi, (u32)(lo >> 32)};
     }
-    __device__ __forceinline__ u64 key(u32 j, int k) const { return top(j) >> (64 - 2 * k); }
     // makes the compiler wait for the loaded words here
     __device__ __forceinline__ void touch() const { __asm__ volatile("" :: "v"(w0), "v"(w1), "v"(w2)); }
     // explicit wait for words requested N vector-memory operations before the most recent one (memory operations of a
@@ -111,20 +123,18 @@ template <> struct Roll<K128> {
         w0 = w[i]; w1 = w[i + 1]; w2 = w[i + 2]; w3 = w[i + 3];
         s = (u32)(p & 31) << 1;
     }
-    __device__ __forceinline__ u64 word(u32 ob, const u64& a, const u64& b) const { return ob ? ((a << ob) | (b >> (64 - ob))) : a; }
-    // j < 32 - ... : the window needs bases [j, j + 64): with s <= 62 and j <= 15 that is inside the four words
-    __device__ __forceinline__ u64 top(u32 j) const {
-        const u32 ob = s + 2 * j;            // < 126 for j < 32
-        const bool hi = ob >= 64;
-        const u32 o = ob & 63;
-        return hi ? word(o, w1, w2) : word(o, w0, w1);
-    }
-    __device__ __forceinline__ K128 key(u32 j, int k) const {
-        const u32 ob = s + 2 * j;
-        const bool hi = ob >= 64;
-        const u32 o = ob & 63;
-        const K128 win{hi ? word(o, w1, w2) : word(o, w0, w1), hi ? word(o, w2, w3) : word(o, w1, w2)};
-        return kshr(win, 128 - 2 * k);
+    // the 160 bits (80 bases) from the load position: 8 starts + 63 bases of the longest k-mer
+    struct Win {
+        u32 d5, d4, d3, d2, d1;
+        template <u32 J> __device__ __forceinline__ u32 top_hi() const { return word_at<J>(d5, d4); }
+        template <u32 J> __device__ __forceinline__ K128 key(int k) const {
+            const K128 win{((u64)word_at<J>(d5, d4) << 32) | word_at<J>(d4, d3), ((u64)word_at<J>(d3, d2) << 32) | word_at<J>(d2, d1)};
+            return kshr(win, 128 - 2 * k);
+        }
+    };
+    __device__ __forceinline__ Win prep() const {
+        const u64 a = funnel64(w0, w1, s), b = funnel64(w1, w2, s), c = funnel64(w2, w3, s);
+        return Win{(u32)(a >> 32), (u32)a, (u32)(b >> 32), (u32)b, (u32)(c >> 32)};
     }
     __device__ __forceinline__ void touch() const { __asm__ volatile("" :: "v"(w0), "v"(w1), "v"(w2), "v"(w3)); }
     template <int N> __device__ __forceinline__ void wait_all_but() {

@@ -296,7 +296,12 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     // every (tile, bucket) run is padded to a multiple of padm + 1 keys (a 128-byte line when the bucket count allows;
     // the padding of one tile must fit the flush passes k_bucket_scatter has beyond KT)
     const u32 line_keys = 128 / KB, pad_room = W == 1 ? 2 * GASM_TILE_WG : GASM_TILE_WG;
-    auto pad_mask = [&](u32 nb) { u32 m = line_keys - 1; while (m && (u64)nb * m > pad_room) m >>= 1; return m; };
+    auto pad_mask = [&](u32 nb) {
+        u32 m = line_keys - 1;
+        if (getenv("GASM_DBG_PADM")) m = std::min<u32>(m, (u32)atoi(getenv("GASM_DBG_PADM")));   // tuning
+        while (m && (u64)nb * m > pad_room) m >>= 1;
+        return m;
+    };
     const ReadSet rs = rd.view();
     const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * 8);
     constexpr u32 SCRATCH_KEYS = 1024 * (GASM_TILE_WG / 64) * 64;   // a line-set per wave of 1024 workgroup slots (k_bucket_scatter)
@@ -322,10 +327,10 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
             GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 4, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
                     bs.d_cube.as<u16>());
         }
-        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(std::min(1024u, std::max(64u, nb))), 0, rs, bbits, padm, bs.d_cube.as<u16>(),
+        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(1024), 0, rs, bbits, padm, bs.d_cube.as<u16>(),
                 bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
-        const size_t lds = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (size_t)nb * 12 + 64;   // KeyTraits<K>::NFL passes
+        const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 12 + 64;   // KeyTraits<K>::NFL passes + trash slots
         // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
         const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 8));
         if (W == 1) {
