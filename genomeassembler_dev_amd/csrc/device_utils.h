@@ -79,6 +79,17 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* s_tmp, u32* total) {
     return base + inc - v;
 }
 
+// Segment-major grids, XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2 (observed
+// behaviour, a speed assumption only), so the C workgroups of a segment get linear ids that are congruent mod 8:
+// everything the segment's kernels gather from — its slice of the sorted k-mers, its links, its contigs — then lives
+// in one L2 instead of being pulled into all eight.  Launch with grid = seg_grid(C, S) (host); false = padding workgroup.
+__device__ __forceinline__ bool seg_chunk(u32 n_segments, u32 chunks, u32* seg, u32* chunk) {
+    const u32 b = blockIdx.x, q = b >> 3;
+    *chunk = q % chunks;
+    *seg = (q / chunks) * 8u + (b & 7u);
+    return *seg < n_segments;
+}
+
 template <class T>
 __device__ __forceinline__ u32 lower_bound_dev(const T* __restrict__ a, u32 lo, u32 hi, T t) {
     while (lo < hi) {

@@ -70,7 +70,7 @@ __global__ void k_pack_ascii(const u8* ascii, u64 nbases, u64* words, u64 nwords
 #define GASM_TILE_WG 512     // threads of a tile workgroup (k_tile_hist, k_bucket_scatter)
 template <class K> __global__ void k_tile_hist(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 n_tiles, u16* tcnt);
 __global__ void k_tile_scan(ReadSet rs, int bbits, u32 padm, const u16* tcnt, u32* toff, u32* hist);
-template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
+template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n, const u32* tail);
 __global__ void k_copy_u64(const u64* a, u64* b, u32 n);
 template <class K>
 __global__ void k_bucket_scatter(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 padm, u32 n_tiles, const u64* bstart, const u32* toff,
@@ -81,15 +81,15 @@ __global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, u32* bucke
                                unsigned long long* stamps);
 template <class K>
 __global__ void k_bucket_gather(const K* keys, const u32* mult, const u64* bstart, const u32* dstart, K* dk_key, u32* dk_cnt);
-template <class K> __global__ void k_node_flags(GraphView gv, u8* eflag);
-template <class K> __global__ void k_edge_next(GraphView gv, const u8* eflag, u32* nxt, u64* link);
-__global__ void k_link_jump(u64* link, u32 n_edges);
+template <class K> __global__ void k_node_flags(GraphView gv, u32 n_segments, u32 chunks, u8* eflag, u64* link, u32* clen);
+template <class K> __global__ void k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u8* eflag, u32* nxt, u64* link);
+__global__ void k_link_jump(GraphView gv, u32 n_segments, u32 chunks, u64* link, const u32* prev_active, u32* active, int jumps);
 __global__ void k_link_rank_seg(GraphView gv, u64* link, int max_rounds);
 __global__ void k_chain_len(const u8* eflag, const u32* nxt, const u64* link, u32* clen, u32 n_edges);
 __global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u32* e_cid, u64* e_coff, u32* seg_ncontig,
                               u64* seg_cbases);
 __global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* clen, const u32* seg_cstart,
-                               const u64* seg_bstart, u32* e_cid, u64* e_coff, u64* c_off);
+                               const u64* seg_bstart, u32* e_cid, u64* e_coff, u64* c_off, u32 n_segments, u32 chunks);
 template <class K>
 __global__ void k_contig_emit(GraphView gv, const u8* eflag, const u64* link, const u64* e_coff, u8* out, u32 n_edges);
 
@@ -103,7 +103,7 @@ __global__ void k_seed_insert(PathSet ps, SeedTable st, const u64* seg_base_off,
 __global__ void k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, u32* poscnt);
 template <class K>
 __global__ void k_score_reads_graph(ReadSet rs, GraphView gv, const u64* link, const u32* e_cid, PathSet ps, const long long* dfix,
-                                    int kmer, u32 reads_per_wg, u32* cnt, unsigned long long* sum);
+                                    int kmer, u32 reads_per_wg, u32 chunks, u32* cnt, unsigned long long* sum);
 __global__ void k_score_finish(PathSet ps, const u32* cnt, const unsigned long long* sum, const long long* dfix, const u64* seg_empty,
                                int kmer, double inv_scale, double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,
                                int32_t* seq_len, u32 n_paths);

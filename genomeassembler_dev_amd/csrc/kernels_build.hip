@@ -156,9 +156,10 @@ __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 p
     }
 }
 
-// Exclusive scan of n u32 into n+1 outputs of type TO; one workgroup of 1024 threads, running carry.
+// Exclusive scan of n u32 into n+1 outputs of type TO; one workgroup of 1024 threads, running carry.  `tail` (optional):
+// one more word copied to out[n + 1], so that a flag can ride to the host behind the scanned array in a single copy.
 template <class TO>
-__global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, TO* __restrict__ out, u32 n) {
+__global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, TO* __restrict__ out, u32 n, const u32* __restrict__ tail) {
     __shared__ u32 s_tmp[16];
     TO carry = 0;
     for (u32 base = 0; base < n; base += 1024) {
@@ -169,10 +170,10 @@ __global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, 
         if (i < n) out[i] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) out[n] = carry;
+    if (threadIdx.x == 0) { out[n] = carry; if (tail) out[n + 1] = (TO)*tail; }
 }
-template __global__ void k_scan_excl<u64>(const u32*, u64*, u32);
-template __global__ void k_scan_excl<u32>(const u32*, u32*, u32);
+template __global__ void k_scan_excl<u64>(const u32*, u64*, u32, const u32*);
+template __global__ void k_scan_excl<u32>(const u32*, u32*, u32, const u32*);
 
 // ================================================================================================================
 // Scatter the k-mers of every tile into their (segment, bucket) ranges — whole cache lines only.
@@ -619,12 +620,14 @@ __device__ __forceinline__ bool kmer_exists(const GraphView& gv, u32 seg, const 
 
 // flag bit0: the edge's source node is a branching node (in != 1 or out != 1); it has out-edges by construction.
 template <class K>
-__global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u8* __restrict__ eflag) {
+__global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u32 n_segments, u32 chunks, u8* __restrict__ eflag,
+                                                        u64* __restrict__ link, u32* __restrict__ clen) {
     const K* dk = reinterpret_cast<const K*>(gv.dk_key);
-    const u32 seg = blockIdx.y;
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 i = lo + blockIdx.x * GASM_WG + threadIdx.x;
+    const u32 i = lo + chunk * GASM_WG + threadIdx.x;
     if (i >= hi) return;
     const K key = dk[i];
     const K u = kshr(key, 2);
@@ -638,21 +641,24 @@ __global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u8* __rest
 #pragma unroll
     for (u64 x = 0; x < 4; ++x) ind += kmer_exists<K>(gv, seg, kor(kshl(key_from_u64<K>(x), sh), u));
     eflag[i] = (ind != 1 || outd != 1) ? 1 : 0;
+    link[i] = ~0ull;      // "no ancestor" until k_edge_next says otherwise
+    clen[i] = 0;
 }
-template __global__ void k_node_flags<u64>(GraphView, u8*);
-template __global__ void k_node_flags<K128>(GraphView, u8*);
+template __global__ void k_node_flags<u64>(GraphView, u32, u32, u8*, u64*, u32*);
+template __global__ void k_node_flags<K128>(GraphView, u32, u32, u8*, u64*, u32*);
 
 // Successor edge of every edge (GASM_NONE32 when the walk stops at its target), and the initial ancestor links:
 // link = ancestor << 32 | done << 31 | distance, done = "the ancestor is the head of the chain".  Heads are their own
 // ancestor at distance 0.  The done bit travels with the link, so pointer doubling needs one gather per round.
 template <class K>
-__global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, const u8* __restrict__ eflag, u32* __restrict__ nxt,
-                                                       u64* __restrict__ link) {
+__global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u8* __restrict__ eflag,
+                                                       u32* __restrict__ nxt, u64* __restrict__ link) {
     const K* dk = reinterpret_cast<const K*>(gv.dk_key);
-    const u32 seg = blockIdx.y;
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 i = lo + blockIdx.x * GASM_WG + threadIdx.x;
+    const u32 i = lo + chunk * GASM_WG + threadIdx.x;
     if (i >= hi) return;
     const K key = dk[i];
     const int sh = 2 * (gv.k - 1);
@@ -668,20 +674,56 @@ __global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, const u8* _
     if (n != GASM_NONE32) link[n] = ((u64)i << 32) | me_head | 1ull;
     if (me_head) link[i] = ((u64)i << 32) | GASM_LINK_DONE;
 }
-template __global__ void k_edge_next<u64>(GraphView, const u8*, u32*, u64*);
-template __global__ void k_edge_next<K128>(GraphView, const u8*, u32*, u64*);
+template __global__ void k_edge_next<u64>(GraphView, u32, u32, const u8*, u32*, u64*);
+template __global__ void k_edge_next<K128>(GraphView, u32, u32, const u8*, u32*, u64*);
 
-// One round of pointer doubling towards the head of the chain.  In place and asynchronous: a link is always a
-// consistent (ancestor, done, distance) triple because it is read and written as one 64-bit word.
-__global__ void __launch_bounds__(GASM_WG) k_link_jump(u64* __restrict__ link, u32 n_edges) {
-    const u32 i = blockIdx.x * GASM_WG + threadIdx.x;
-    if (i >= n_edges) return;
-    const u64 l = link[i];
-    const u32 a = (u32)(l >> 32);
-    if (a == GASM_NONE32 || (l & GASM_LINK_DONE)) return;
-    const u64 la = *reinterpret_cast<volatile const u64*>(&link[a]);
-    if ((u32)(la >> 32) == GASM_NONE32) return;
-    link[i] = (la & (0xFFFFFFFF00000000ull | GASM_LINK_DONE)) | (u64)(((u32)l + (u32)la) & 0x7FFFFFFFu);
+// Pointer doubling towards the head of the chain, `jumps` steps per launch.  In place and asynchronous: a link is
+// always a consistent (ancestor, done, distance) triple because it is read and written as one 64-bit word, and a stale
+// triple is still a true statement about the chain — so neither the steps inside a launch nor the workgroups need to
+// be in step; what is guaranteed per launch is that every link's span grows by the factor jumps + 1 (each step adds at
+// least the span its ancestor had before the launch).  Whole-GPU launches beat one workgroup per segment: a CU resolves about one scattered address per clock,
+// and a segment's ~15 rounds of gathers through a single CU took 0.28 ms against 5 launches of ~10 us here.
+// `active` (one word per launch, zeroed by the host): set when some link is still short of its head; a launch returns
+// at once when the previous one left it clear.  Members of isolated cycles never finish: the number of launches bounds them.
+#define GASM_JUMP_ILP 4      // links per thread, advanced together: the steps are dependent gathers, so the kernel lives on loads in flight
+__global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segments, u32 chunks, u64* __restrict__ link,
+                                                       const u32* __restrict__ prev_active, u32* __restrict__ active, int jumps) {
+    if (prev_active && *prev_active == 0) return;
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;       // a segment's links stay in one XCD's L2
+    const u32 nb = 1u << gv.bbits;
+    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
+    const u32 i0 = lo + chunk * (GASM_WG * GASM_JUMP_ILP) + threadIdx.x;
+    u64 l[GASM_JUMP_ILP];
+    bool act[GASM_JUMP_ILP];
+#pragma unroll
+    for (int q = 0; q < GASM_JUMP_ILP; ++q) {
+        const u32 i = i0 + q * GASM_WG;
+        l[q] = i < hi ? link[i] : ~0ull;
+        act[q] = (u32)(l[q] >> 32) != GASM_NONE32 && !(l[q] & GASM_LINK_DONE);
+    }
+    const bool mine = act[0] || act[1] || act[2] || act[3];
+    for (int j = 0; j < jumps; ++j) {
+        u64 la[GASM_JUMP_ILP];
+#pragma unroll
+        for (int q = 0; q < GASM_JUMP_ILP; ++q)      // may be stale: fine
+            la[q] = act[q] ? __hip_atomic_load(&link[(u32)(l[q] >> 32)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+#pragma unroll
+        for (int q = 0; q < GASM_JUMP_ILP; ++q) {
+            if (!act[q]) continue;
+            if ((u32)(la[q] >> 32) == GASM_NONE32) { act[q] = false; continue; }
+            l[q] = (la[q] & (0xFFFFFFFF00000000ull | GASM_LINK_DONE)) | (u64)(((u32)l[q] + (u32)la[q]) & 0x7FFFFFFFu);
+            if (l[q] & GASM_LINK_DONE) act[q] = false;
+        }
+    }
+    if (!mine) return;
+    bool open = false;
+#pragma unroll
+    for (int q = 0; q < GASM_JUMP_ILP; ++q) {
+        const u32 i = i0 + q * GASM_WG;
+        if (i < hi && (u32)(l[q] >> 32) != GASM_NONE32) { link[i] = l[q]; open = open || !(l[q] & GASM_LINK_DONE); }
+    }
+    if (open) *active = 1u;
 }
 
 // All rounds of pointer doubling for one segment inside one workgroup (no launch per round, early exit when every
@@ -776,11 +818,12 @@ __global__ void __launch_bounds__(1024) k_contig_scan(GraphView gv, const u8* __
 __global__ void __launch_bounds__(GASM_WG) k_contig_place(GraphView gv, const u8* __restrict__ eflag, const u32* __restrict__ clen,
                                                           const u32* __restrict__ seg_cstart, const u64* __restrict__ seg_bstart,
                                                           u32* __restrict__ e_cid, u64* __restrict__ e_coff,
-                                                          u64* __restrict__ c_off) {
-    const u32 seg = blockIdx.y;
+                                                          u64* __restrict__ c_off, u32 n_segments, u32 chunks) {
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 i = lo + blockIdx.x * GASM_WG + threadIdx.x;
+    const u32 i = lo + chunk * GASM_WG + threadIdx.x;
     if (i >= hi || !(eflag[i] & 1)) return;
     const u32 cid = seg_cstart[seg] + e_cid[i];
     const u64 off = seg_bstart[seg] + e_coff[i];

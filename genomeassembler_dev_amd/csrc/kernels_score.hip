@@ -137,17 +137,18 @@ __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& g
 // integer additions commute, so the result does not depend on the order the reads arrive in (bit-reproducible without a
 // fixed reduction tree).  A workgroup keeps the accumulators of its segment's paths in LDS (ds_add_u32 / ds_add_u64) and
 // flushes the non-zero ones with global atomics at the end; segments with more paths than fit go to global atomics
-// directly.  blockIdx.y = segment, blockIdx.x = slice of the segment's reads.
+// directly.  A workgroup = one slice of one segment's reads (seg_chunk, device_utils.h).
 #define GASM_SCORE_PATH_CAP 6144
 template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, GraphView gv, const u64* __restrict__ link,
                                                                const u32* __restrict__ e_cid, PathSet ps,
-                                                               const long long* __restrict__ dfix, int kmer, u32 reads_per_wg,
+                                                               const long long* __restrict__ dfix, int kmer, u32 reads_per_wg, u32 chunks,
                                                                u32* __restrict__ cnt, unsigned long long* __restrict__ sum) {
     __shared__ unsigned long long s_sum[GASM_SCORE_PATH_CAP];
     __shared__ u32 s_cnt[GASM_SCORE_PATH_CAP];
-    const u32 seg = blockIdx.y;
-    const u64 r0 = rs.seg_read_off[seg] + (u64)blockIdx.x * reads_per_wg;
+    u32 seg, chunk;
+    if (!seg_chunk(rs.n_segments, chunks, &seg, &chunk)) return;      // a segment's graph and contigs stay in one XCD's L2
+    const u64 r0 = rs.seg_read_off[seg] + (u64)chunk * reads_per_wg;
     const u64 rseg_end = rs.seg_read_off[seg + 1];
     if (r0 >= rseg_end) return;
     const u64 r1 = r0 + reads_per_wg < rseg_end ? r0 + reads_per_wg : rseg_end;
@@ -174,9 +175,9 @@ __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, Graph
     }
 }
 
-template __global__ void k_score_reads_graph<u64>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32*,
+template __global__ void k_score_reads_graph<u64>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32, u32*,
                                                   unsigned long long*);
-template __global__ void k_score_reads_graph<K128>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32*,
+template __global__ void k_score_reads_graph<K128>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32, u32*,
                                                    unsigned long long*);
 
 // Fixed-point sums -> the reference's per-path numbers.  `seg_empty`: empty reads of the path's segment, each a hit at

@@ -21,6 +21,9 @@ __global__ void k_add_empty_reads(PathSet ps, const u64* __restrict__ seg_empty,
     else total[p] += e;   // an empty path has no position counter: carried as an extra addend
 }
 
+// grid of the segment-major kernels (seg_chunk, device_utils.h): 8 x chunks x ceil(S / 8) workgroups
+static dim3 seg_grid(u32 chunks, u32 S) { return dim3(8u * chunks * ((S + 7u) / 8u)); }
+
 static int h2d(gasm_ctx* ctx, DBuf& b, const void* src, size_t bytes) {
     GCHK(b.ensure(bytes ? bytes : 8));
     if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -45,9 +48,8 @@ static int d2h_sync(gasm_ctx* ctx, void* dst, const void* src, size_t bytes) {
 static int pack_ascii(gasm_ctx* ctx, const u8* d_ascii, u64 nbases, DBuf& words, u32* d_err) {
     const u64 nw = (nbases + 31) / 32;
     GCHK(words.ensure((nw + 4) * 8));     // four zero padding words: a 128-bit rolling window reads up to three words ahead
-    HIPCHK(hipMemsetAsync((u64*)words.p + nw, 0, 32, ctx->stream));
-    if (nw) GLAUNCH(ctx, "k_pack_ascii", k_pack_ascii, dim3(ceil_div_u64(nw, GASM_WG)), dim3(GASM_WG), 0, d_ascii, nbases,
-                    words.as<u64>(), nw, d_err);
+    // (the kernel also writes the padding words: positions past the last base pack as zero)
+    GLAUNCH(ctx, "k_pack_ascii", k_pack_ascii, dim3(ceil_div_u64(nw + 4, GASM_WG)), dim3(GASM_WG), 0, d_ascii, nbases, words.as<u64>(), nw + 4, d_err);
     return GASM_OK;
 }
 
@@ -265,7 +267,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
         while (bbits < bb_cap && (dest >> bbits) > 900) ++bbits;
     }
-    GCHK(bs.d_flags.ensure(64));
+    GCHK(bs.d_flags.ensure(256));      // [0] bucket overflow, [16..] the list-ranking launches' "still active" words
     bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
     // small (2048-slot) LDS tables when the expected number of distinct k-mers per bucket is small: more workgroups per CU
     bool small_tbl;
@@ -319,7 +321,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
         GCHK(bs.d_dstart.ensure(((size_t)nbt + 2) * 4));
-        HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 64, ctx->stream));
+        HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 256, ctx->stream));
         if (W == 1) {
             GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 4, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
                     bs.d_cube.as<u16>());
@@ -329,7 +331,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         }
         GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(1024), 0, rs, bbits, padm, bs.d_cube.as<u16>(),
                 bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
-        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
+        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr);
         const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 12 + 64;   // KeyTraits<K>::NFL passes + trash slots
         // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
         const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 8));
@@ -374,11 +376,10 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
             fprintf(stderr, "[dedup stamps, 100 MHz ticks per workgroup] init %.1f  first-iter %.1f  stream %.1f  barrier %.1f  order %.1f  writeback %.1f\n",
                     (double)h[0] / nbt, (double)h[1] / nbt, (double)h[2] / nbt, (double)h[3] / nbt, (double)h[4] / nbt, (double)h[5] / nbt);
         }
-        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt);
+        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt, bs.d_flags.as<u32>());
         bs.h_dstart.resize((size_t)nbt + 1);
         u32 hflags[2] = {0, 0};
         // the overflow flag rides behind the directory so one copy + one wait fetches both
-        HIPCHK(hipMemcpyAsync(bs.d_dstart.as<u32>() + nbt + 1, bs.d_flags.p, 4, hipMemcpyDeviceToDevice, ctx->stream));
         bs.h_dstart.resize((size_t)nbt + 2);
         GCHK(d2h_sync(ctx, bs.h_dstart.data(), bs.d_dstart.p, ((size_t)nbt + 2) * 4));
         hflags[0] = bs.h_dstart[(size_t)nbt + 1];
@@ -418,8 +419,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     GCHK(bs.d_ecoff.ensure((size_t)D * 8));
     GCHK(bs.d_seg_cbases.ensure((size_t)S * 8 + (size_t)S * 4));   // u64 bases[S] then u32 counts[S]: one read-back
     u32* d_seg_ncontig = reinterpret_cast<u32*>(bs.d_seg_cbases.as<u64>() + S);
-    HIPCHK(hipMemsetAsync(bs.d_link.p, 0xFF, (size_t)D * 8, ctx->stream));
-    HIPCHK(hipMemsetAsync(bs.d_clen.p, 0, (size_t)D * 4, ctx->stream));
+    // (k_node_flags also initialises link = none and clen = 0 for its edge)
     GraphView gv;
     gv.dk_key = bs.d_dk_key.p;
     gv.dstart = bs.d_dstart.as<u32>();
@@ -427,23 +427,31 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     gv.k = k;
     gv.bbits = bbits;
     gv.fbits = bs.fbits;
-    const dim3 grid_seg(ceil_div_u64(maxD, GASM_WG), S);
+    const u32 dchunks = (u32)ceil_div_u64(maxD, GASM_WG);     // workgroups per segment of the per-edge kernels
+    const dim3 grid_seg = seg_grid(dchunks, S);
     const dim3 grid_all(ceil_div_u64(D, GASM_WG));
     if (W == 1) {
-        GLAUNCH(ctx, "k_node_flags", k_node_flags<u64>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>());
-        GLAUNCH(ctx, "k_edge_next", k_edge_next<u64>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
+        GLAUNCH(ctx, "k_node_flags", k_node_flags<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
+        GLAUNCH(ctx, "k_edge_next", k_edge_next<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
     } else {
-        GLAUNCH(ctx, "k_node_flags", k_node_flags<K128>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>());
-        GLAUNCH(ctx, "k_edge_next", k_edge_next<K128>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
+        GLAUNCH(ctx, "k_node_flags", k_node_flags<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
+        GLAUNCH(ctx, "k_edge_next", k_edge_next<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
     }
     int rounds = 1;
     while ((1ull << rounds) < (u64)maxD) ++rounds;
     rounds += 1;
-    if (maxD <= (1u << 18)) {
-        // one workgroup per segment runs every round (early exit); enough for segments up to 256k distinct k-mers
+    if (getenv("GASM_RANK_SEG") && maxD <= (1u << 18)) {
+        // (kept for comparison) one workgroup per segment runs every round with early exit
         GLAUNCH(ctx, "k_link_rank_seg", k_link_rank_seg, dim3(S), dim3(1024), 0, gv, bs.d_link.as<u64>(), rounds + 1);
     } else {
-        for (int r = 0; r < rounds; ++r) GLAUNCH(ctx, "k_link_jump", k_link_jump, grid_all, dim3(GASM_WG), 0, bs.d_link.as<u64>(), D);
+        // whole-GPU launches of `jumps` doubling steps each; a launch returns at once when its predecessor found every chain done
+        // (spans grow by at least jumps + 1 = 5 per launch: log2(5) > 2.3 rounds' worth)
+        const int jumps = 4, launches = (rounds * 10 + 22) / 23 + 1;
+        if (launches > 40) { gasm_set_error("segment too large for the list-ranking flags"); return GASM_ERR_CAPACITY; }
+        u32* act = bs.d_flags.as<u32>() + 16;     // zeroed with the flags at the start of the build
+        const u32 jchunks = (u32)ceil_div_u64(maxD, GASM_WG * 4);      // GASM_JUMP_ILP links per thread
+        for (int r = 0; r < launches; ++r)
+            GLAUNCH(ctx, "k_link_jump", k_link_jump, seg_grid(jchunks, S), dim3(GASM_WG), 0, gv, S, jchunks, bs.d_link.as<u64>(), r ? act + r - 1 : nullptr, act + r, jumps);
     }
     GLAUNCH(ctx, "k_chain_len", k_chain_len, grid_all, dim3(GASM_WG), 0, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>(),
             bs.d_clen.as<u32>(), D);
@@ -465,7 +473,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     GCHK(bs.d_contig_ascii.ensure(bs.contig_bases + 64));
     if (bs.n_contigs) {
         GLAUNCH(ctx, "k_contig_place", k_contig_place, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
-                bs.d_seg_cstart.as<u32>(), bs.d_seg_bstart.as<u64>(), bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_c_off.as<u64>());
+                bs.d_seg_cstart.as<u32>(), bs.d_seg_bstart.as<u64>(), bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_c_off.as<u64>(), S, dchunks);
     }
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, ctx->stream, bs.d_c_off.as<u64>() + bs.n_contigs, bs.contig_bases);
     if (bs.n_contigs) {
@@ -583,6 +591,8 @@ int ScoreTable::set_standard(gasm_ctx* ctx, const double* t) {
     GCHK(h2d(ctx, d_row, row.data(), row.size() * 4));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     h_prob = prob;
+    h_absmax = 0;
+    for (double v : h_prob) h_absmax = std::max(h_absmax, std::fabs(v));
     fix_shift = -1;
     return GASM_OK;
 }
@@ -590,8 +600,7 @@ int ScoreTable::set_standard(gasm_ctx* ctx, const double* t) {
 // 64-bit fixed-point copy of the table for the batch scorer: round(prob * 2^shift), shift chosen so that the sum over
 // `max_terms` reads cannot overflow 62 bits.
 int ScoreTable::set_fixed(gasm_ctx* ctx, u64 max_terms) {
-    double mx = 0;
-    for (double v : h_prob) mx = std::max(mx, std::fabs(v));
+    const double mx = h_absmax;
     int shift = 62;
     if (mx > 0) {
         const double need = std::log2(mx * (double)std::max<u64>(1, max_terms));
@@ -626,12 +635,15 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
     const u32 S = rd.n_segments, P = dp.n_paths;
     const u64 TB = dp.total_bases;
     GCHK(ss.d_poscnt.ensure((TB + 1) * 4));
-    GCHK(ss.d_total.ensure(((size_t)P + 1) * 4));
+    // per-path counters and, behind them, the 64-bit fixed-point sums of the graph scorer: one allocation, one memset
+    const size_t fx_off = (((size_t)P + 1) * 4 + 15) & ~(size_t)15;
+    GCHK(ss.d_total.ensure(fx_off + ((size_t)P + 1) * 8));
     GCHK(ss.d_out_f64.ensure(((size_t)P + 1) * 8 * 3));
     GCHK(ss.d_out_i32.ensure(((size_t)P + 1) * 4 * 2));
     const bool use_graph = graph && P && TB && rd.n_reads > rd.n_empty && rd.min_len >= (u32)graph->k && graph->d_total;
     if (!use_graph) HIPCHK(hipMemsetAsync(ss.d_poscnt.p, 0, (TB + 1) * 4, ctx->stream));
-    HIPCHK(hipMemsetAsync(ss.d_total.p, 0, ((size_t)P + 1) * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ss.d_total.p, 0, use_graph ? fx_off + ((size_t)P + 1) * 8 : ((size_t)P + 1) * 4, ctx->stream));
+    unsigned long long* const d_fx = reinterpret_cast<unsigned long long*>(static_cast<char*>(ss.d_total.p) + fx_off);
     const PathSet ps = dp.view();
     const int w = (int)std::min<u32>(32, rd.min_len);
     if (use_graph) {
@@ -647,17 +659,16 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
         u64 max_reads = 0;
         for (u32 s = 0; s < S; ++s) max_reads = std::max(max_reads, rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]);
         GCHK(const_cast<ScoreTable&>(tb).set_fixed(ctx, max_reads));
-        GCHK(ss.d_fxsum.ensure(((size_t)P + 1) * 8));
-        HIPCHK(hipMemsetAsync(ss.d_fxsum.p, 0, ((size_t)P + 1) * 8, ctx->stream));
         const u32 reads_per_wg = 256;     // one read per thread: the match is a chain of dependent loads
+        const u32 rchunks = (u32)ceil_div_u64(max_reads, reads_per_wg);
         if (graph->words == 1) {
-            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<u64>, dim3(ceil_div_u64(max_reads, reads_per_wg), S), dim3(GASM_WG), 0, rd.view(),
-                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, ss.d_total.as<u32>(),
-                    ss.d_fxsum.as<unsigned long long>());
+            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<u64>, seg_grid(rchunks, S), dim3(GASM_WG), 0, rd.view(),
+                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, ss.d_total.as<u32>(),
+                    d_fx);
         } else {
-            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<K128>, dim3(ceil_div_u64(max_reads, reads_per_wg), S), dim3(GASM_WG), 0, rd.view(),
-                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, ss.d_total.as<u32>(),
-                    ss.d_fxsum.as<unsigned long long>());
+            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<K128>, seg_grid(rchunks, S), dim3(GASM_WG), 0, rd.view(),
+                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, ss.d_total.as<u32>(),
+                    d_fx);
         }
     } else if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
         // per-segment seed tables: power-of-two, at least twice the number of path positions
@@ -703,7 +714,7 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
         const u64* d_se = nullptr;
         if (rd.n_empty) { GCHK(h2d(ctx, ss.d_seg_empty, rd.h_seg_empty.data(), (size_t)S * 8)); d_se = ss.d_seg_empty.as<u64>(); }
         GLAUNCH(ctx, "k_score_finish", k_score_finish, dim3(ceil_div_u64(P, GASM_WG)), dim3(GASM_WG), 0, ps, ss.d_total.as<u32>(),
-                ss.d_fxsum.as<unsigned long long>(), tb.d_fix.as<long long>(), d_se, kmer, std::ldexp(1.0, -tb.fix_shift), o_bp, o_nf, o_nl,
+                d_fx, tb.d_fix.as<long long>(), d_se, kmer, std::ldexp(1.0, -tb.fix_shift), o_bp, o_nf, o_nl,
                 o_br, o_ln, P);
     } else if (P) {
         GLAUNCH(ctx, "k_path_reduce", k_path_reduce, dim3(P), dim3(GASM_WG), 0, ps, ss.d_poscnt.as<u32>(),
