@@ -80,9 +80,12 @@ template <class K, int TBL>
 __global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits, int dbg,
                                unsigned long long* stamps);
 template <class K>
-__global__ void k_bucket_gather(const K* keys, const u32* mult, const u64* bstart, const u32* dstart, K* dk_key, u32* dk_cnt);
-template <class K> __global__ void k_node_flags(GraphView gv, u32 n_segments, u32 chunks, u8* eflag, u64* link, u32* clen);
-template <class K> __global__ void k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u8* eflag, u32* nxt, u64* link);
+__global__ void k_bucket_gather(const K* keys, const u32* mult, const u64* bstart, const u32* dstart, K* dk_key, u32* dk_cnt, u32* claim, u8* eflag);
+template <class K> __global__ void k_edge_target(GraphView gv, u32 n_segments, u32 chunks, u32* tgt, u32* claim);
+__global__ void k_edge_multi(GraphView gv, u32 n_segments, u32 chunks, const u32* tgt, const u32* claim, u8* eflag);
+template <class K>
+__global__ void k_node_flags(GraphView gv, u32 n_segments, u32 chunks, const u32* claim, u8* eflag, u64* link, u32* clen);
+__global__ void k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u32* tgt, const u8* eflag, u32* nxt, u64* link);
 __global__ void k_link_jump(GraphView gv, u32 n_segments, u32 chunks, u64* link, const u32* prev_active, u32* active, int jumps);
 __global__ void k_link_rank_seg(GraphView gv, u64* link, int max_rounds);
 __global__ void k_chain_len(const u8* eflag, const u32* nxt, const u64* link, u32* clen, u32 n_edges);

@@ -598,14 +598,20 @@ template __global__ void k_bucket_dedup<K128, 2048>(K128*, u32*, const u64*, u32
 template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const K* __restrict__ keys, const u32* __restrict__ mult,
                                                            const u64* __restrict__ bstart, const u32* __restrict__ dstart,
-                                                           K* __restrict__ dk_key, u32* __restrict__ dk_cnt) {
+                                                           K* __restrict__ dk_key, u32* __restrict__ dk_cnt, u32* __restrict__ claim,
+                                                           u8* __restrict__ eflag) {
     const u32 bucket = blockIdx.x;
     const u64 src = bstart[bucket];
     const u32 dst = dstart[bucket], d = dstart[bucket + 1] - dst;
-    for (u32 i = threadIdx.x; i < d; i += GASM_WG) { dk_key[dst + i] = keys[src + i]; dk_cnt[dst + i] = mult[src + i]; }
+    for (u32 i = threadIdx.x; i < d; i += GASM_WG) {
+        dk_key[dst + i] = keys[src + i];
+        dk_cnt[dst + i] = mult[src + i];
+        claim[dst + i] = GASM_NONE32;     // initial state of the degree kernels (k_edge_target)
+        eflag[dst + i] = 0;
+    }
 }
-template __global__ void k_bucket_gather<u64>(const u64*, const u32*, const u64*, const u32*, u64*, u32*);
-template __global__ void k_bucket_gather<K128>(const K128*, const u32*, const u64*, const u32*, K128*, u32*);
+template __global__ void k_bucket_gather<u64>(const u64*, const u32*, const u64*, const u32*, u64*, u32*, u32*, u8*);
+template __global__ void k_bucket_gather<K128>(const K128*, const u32*, const u64*, const u32*, K128*, u32*, u32*, u8*);
 
 // ================================================================================================================
 // Graph over the sorted distinct k-mers (= distinct edges) of each segment.  Edge i: key = x·M·y, source node
@@ -618,10 +624,17 @@ __device__ __forceinline__ bool kmer_exists(const GraphView& gv, u32 seg, const 
     return j < hi && keq(reinterpret_cast<const K*>(gv.dk_key)[j], t);
 }
 
-// flag bit0: the edge's source node is a branching node (in != 1 or out != 1); it has out-edges by construction.
+// Degrees without counting.  Every edge looks up the first out-edge j of its target node once (k_edge_target) and
+// writes its own index into claim[j]; whichever edge wins, an edge that later finds somebody else's index there
+// (k_edge_multi) knows the node has a second in-edge and sets bit 1 of eflag[j].  So for the node whose out-edges
+// start at r: in-degree 0 <=> claim[r] untouched, >= 2 <=> bit 1 of eflag[r], else 1 — plain stores only, one lookup
+// per edge instead of the four "does x.u exist" lookups of a direct in-degree count.
+//   eflag bit0: the edge's source node is a branching node (in != 1 or out != 1); it has out-edges by construction.
+//   eflag bit1: (on the first out-edge of a node) the node has two or more in-edges.
+// k_bucket_gather initialises claim = none and eflag = 0.
 template <class K>
-__global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u32 n_segments, u32 chunks, u8* __restrict__ eflag,
-                                                        u64* __restrict__ link, u32* __restrict__ clen) {
+__global__ void __launch_bounds__(GASM_WG) k_edge_target(GraphView gv, u32 n_segments, u32 chunks, u32* __restrict__ tgt,
+                                                         u32* __restrict__ claim) {
     const K* dk = reinterpret_cast<const K*>(gv.dk_key);
     u32 seg, chunk;
     if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
@@ -629,53 +642,71 @@ __global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u32 n_segm
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
     const u32 i = lo + chunk * GASM_WG + threadIdx.x;
     if (i >= hi) return;
-    const K key = dk[i];
-    const K u = kshr(key, 2);
-    // out-degree of u: the run of keys sharing key>>2 is contiguous in the sorted list
-    u32 outd = 1;
-    for (u32 j = i; j > lo && keq(kshr(dk[j - 1], 2), u); --j) ++outd;
-    for (u32 j = i + 1; j < hi && keq(kshr(dk[j], 2), u); ++j) ++outd;
-    // in-degree of u: distinct k-mers x·u
-    u32 ind = 0;
-    const int sh = 2 * (gv.k - 1);
-#pragma unroll
-    for (u64 x = 0; x < 4; ++x) ind += kmer_exists<K>(gv, seg, kor(kshl(key_from_u64<K>(x), sh), u));
-    eflag[i] = (ind != 1 || outd != 1) ? 1 : 0;
+    const K v = klowbits(dk[i], 2 * (gv.k - 1));
+    // the run of v may continue into the next bucket only if bbits > 2(k-1), which the host never chooses
+    u32 bhi;
+    const u32 j = graph_lower_bound<K>(gv, seg, kshl(v, 2), &bhi);      // smallest k-mer with prefix v
+    const bool valid = j < bhi && keq(kshr(dk[j], 2), v);
+    tgt[i] = valid ? j : GASM_NONE32;
+    if (valid) claim[j] = i;
+}
+template __global__ void k_edge_target<u64>(GraphView, u32, u32, u32*, u32*);
+template __global__ void k_edge_target<K128>(GraphView, u32, u32, u32*, u32*);
+
+__global__ void __launch_bounds__(GASM_WG) k_edge_multi(GraphView gv, u32 n_segments, u32 chunks, const u32* __restrict__ tgt,
+                                                        const u32* __restrict__ claim, u8* __restrict__ eflag) {
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
+    const u32 nb = 1u << gv.bbits;
+    const u32 i = gv.dstart[seg * nb] + chunk * GASM_WG + threadIdx.x;
+    if (i >= gv.dstart[(seg + 1) * nb]) return;
+    const u32 j = tgt[i];
+    if (j != GASM_NONE32 && claim[j] != i) eflag[j] = 2;
+}
+
+template <class K>
+__global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u32 n_segments, u32 chunks, const u32* __restrict__ claim,
+                                                        u8* __restrict__ eflag, u64* __restrict__ link, u32* __restrict__ clen) {
+    const K* dk = reinterpret_cast<const K*>(gv.dk_key);
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
+    const u32 nb = 1u << gv.bbits;
+    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
+    const u32 i = lo + chunk * GASM_WG + threadIdx.x;
+    if (i >= hi) return;
+    const K u = kshr(dk[i], 2);
+    // out-degree of u: the run of keys sharing key>>2 is contiguous in the sorted list; r = its first edge
+    u32 r = i;
+    while (r > lo && keq(kshr(dk[r - 1], 2), u)) --r;
+    u32 e = i + 1;
+    while (e < hi && keq(kshr(dk[e], 2), u)) ++e;
+    const u32 outd = e - r;
+    const bool in_one = claim[r] != GASM_NONE32 && !(eflag[r] & 2);
+    eflag[i] = (eflag[i] & 2) | ((!in_one || outd != 1) ? 1 : 0);
     link[i] = ~0ull;      // "no ancestor" until k_edge_next says otherwise
     clen[i] = 0;
 }
-template __global__ void k_node_flags<u64>(GraphView, u32, u32, u8*, u64*, u32*);
-template __global__ void k_node_flags<K128>(GraphView, u32, u32, u8*, u64*, u32*);
+template __global__ void k_node_flags<u64>(GraphView, u32, u32, const u32*, u8*, u64*, u32*);
+template __global__ void k_node_flags<K128>(GraphView, u32, u32, const u32*, u8*, u64*, u32*);
 
 // Successor edge of every edge (GASM_NONE32 when the walk stops at its target), and the initial ancestor links:
 // link = ancestor << 32 | done << 31 | distance, done = "the ancestor is the head of the chain".  Heads are their own
 // ancestor at distance 0.  The done bit travels with the link, so pointer doubling needs one gather per round.
-template <class K>
-__global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u8* __restrict__ eflag,
-                                                       u32* __restrict__ nxt, u64* __restrict__ link) {
-    const K* dk = reinterpret_cast<const K*>(gv.dk_key);
+// (nxt may be the array claim lived in: claim is dead by now.)
+__global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u32* __restrict__ tgt,
+                                                       const u8* __restrict__ eflag, u32* __restrict__ nxt, u64* __restrict__ link) {
     u32 seg, chunk;
     if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
     const u32 nb = 1u << gv.bbits;
-    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 i = lo + chunk * GASM_WG + threadIdx.x;
-    if (i >= hi) return;
-    const K key = dk[i];
-    const int sh = 2 * (gv.k - 1);
-    const K v = klowbits(key, sh);
-    const K t = kshl(v, 2);  // smallest k-mer with prefix v
-    // the run of v may continue into the next bucket only if bbits > 2(k-1), which the host never chooses
-    u32 bhi;
-    const u32 j = graph_lower_bound<K>(gv, seg, t, &bhi);
-    u32 n = GASM_NONE32;
-    if (j < bhi && keq(kshr(dk[j], 2), v) && !(eflag[j] & 1)) n = j;  // v has out-edges and is not branching
+    const u32 i = gv.dstart[seg * nb] + chunk * GASM_WG + threadIdx.x;
+    if (i >= gv.dstart[(seg + 1) * nb]) return;
+    const u32 j = tgt[i];
+    const u32 n = (j != GASM_NONE32 && !(eflag[j] & 1)) ? j : GASM_NONE32;   // the target has out-edges and is not branching
     nxt[i] = n;
     const u64 me_head = (eflag[i] & 1) ? GASM_LINK_DONE : 0ull;
     if (n != GASM_NONE32) link[n] = ((u64)i << 32) | me_head | 1ull;
     if (me_head) link[i] = ((u64)i << 32) | GASM_LINK_DONE;
 }
-template __global__ void k_edge_next<u64>(GraphView, u32, u32, const u8*, u32*, u64*);
-template __global__ void k_edge_next<K128>(GraphView, u32, u32, const u8*, u32*, u64*);
 
 // Pointer doubling towards the head of the chain, `jumps` steps per launch.  In place and asynchronous: a link is
 // always a consistent (ancestor, done, distance) triple because it is read and written as one 64-bit word, and a stale
@@ -790,28 +821,56 @@ __global__ void __launch_bounds__(GASM_WG) k_chain_len(const u8* __restrict__ ef
 }
 
 // Per segment: rank of every head among the segment's heads and the base offset of its contig inside the segment
-// (contig length = k-1 + chain length).  One workgroup of 1024 threads per segment.
+// (contig length = k-1 + chain length).  One workgroup of 1024 threads per segment; each of the 16 waves owns a
+// contiguous sixteenth of the edges and scans it on its own (DPP scans with a running carry, no barriers), the wave
+// totals meet once in LDS, and a second sweep adds the offsets.
 __global__ void __launch_bounds__(1024) k_contig_scan(GraphView gv, const u8* __restrict__ eflag, const u32* __restrict__ clen,
                                                       u32* __restrict__ e_cid, u64* __restrict__ e_coff,
                                                       u32* __restrict__ seg_ncontig, u64* __restrict__ seg_cbases) {
-    __shared__ u32 s_tmp[16];
+    __shared__ u32 s_cnt[16];
+    __shared__ u64 s_bas[16];
     const u32 seg = blockIdx.x;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
+    const u32 wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const u32 per = ((hi - lo + 15) / 16 + 63) & ~63u;          // edges per wave, whole wave-rows
+    const u32 wa = min(hi, lo + wv * per), wb = min(hi, wa + per);
     u32 ccarry = 0;
     u64 bcarry = 0;
-    for (u32 base = lo; base < hi; base += 1024) {
-        const u32 i = base + threadIdx.x;
-        const bool head = i < hi && (eflag[i] & 1);
-        const u32 len = head ? (u32)(gv.k - 1) + clen[i] : 0u;
-        u32 ctot, btot;
-        const u32 cex = block_excl_scan<1024>(head ? 1u : 0u, s_tmp, &ctot);
-        const u32 bex = block_excl_scan<1024>(len, s_tmp, &btot);  // < 2^32 per 1024 edges for any sane contig
-        if (head) { e_cid[i] = ccarry + cex; e_coff[i] = bcarry + bex; }
-        ccarry += ctot;
-        bcarry += btot;
+    for (u32 base = wa; base < wb; base += 256) {
+        u8 ef[4];
+        u32 cl[4];
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) {                            // eight loads in flight, then the scans
+            const u32 i = base + q * 64 + ln;
+            ef[q] = i < wb ? eflag[i] : (u8)0;
+            cl[q] = i < wb ? clen[i] : 0u;
+        }
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) {
+            const u32 i = base + q * 64 + ln;
+            const bool head = ef[q] & 1;
+            const u32 len = head ? (u32)(gv.k - 1) + cl[q] : 0u;
+            const u32 cinc = wave_incl_scan(head ? 1u : 0u);
+            const u32 binc = wave_incl_scan(len);                // < 2^32 per 64 edges for any sane contig
+            if (head) { e_cid[i] = ccarry + cinc - 1; e_coff[i] = bcarry + binc - len; }
+            ccarry += wave_last(cinc);
+            bcarry += wave_last(binc);
+        }
     }
-    if (threadIdx.x == 0) { seg_ncontig[seg] = ccarry; seg_cbases[seg] = bcarry; }
+    if (ln == 0) { s_cnt[wv] = ccarry; s_bas[wv] = bcarry; }
+    __syncthreads();
+    u32 cbefore = 0, ctot = 0;
+    u64 bbefore = 0, btot = 0;
+#pragma unroll
+    for (u32 w = 0; w < 16; ++w) {
+        if (w < wv) { cbefore += s_cnt[w]; bbefore += s_bas[w]; }
+        ctot += s_cnt[w]; btot += s_bas[w];
+    }
+    if (wv)     // heads were only just written by this same thread: plain read-modify-write
+        for (u32 i = wa + ln; i < wb; i += 64)
+            if (eflag[i] & 1) { e_cid[i] += cbefore; e_coff[i] += bbefore; }
+    if (threadIdx.x == 0) { seg_ncontig[seg] = ctot; seg_cbases[seg] = btot; }
 }
 
 // Heads: make contig ids and offsets global; record offset and length per contig.

@@ -403,23 +403,23 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     if (D == 0) return GASM_OK;
     GCHK(bs.d_dk_key.ensure((size_t)D * KB));
     GCHK(bs.d_dk_cnt.ensure((size_t)D * 4));
-    if (W == 1) {
-        GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<u64>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<u64>(), bs.d_dk_cnt.as<u32>());
-    } else {
-        GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<K128>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<K128>(), bs.d_dk_cnt.as<u32>());
-    }
-    // ---- graph
     GCHK(bs.d_eflag.ensure(D));
     GCHK(bs.d_nxt.ensure((size_t)D * 4));
+    u32* const d_claim = bs.d_nxt.as<u32>();      // claim words of the degree kernels live in nxt until k_edge_next overwrites them
+    if (W == 1) {
+        GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<u64>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<u64>(), bs.d_dk_cnt.as<u32>(), d_claim, bs.d_eflag.as<u8>());
+    } else {
+        GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<K128>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
+                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<K128>(), bs.d_dk_cnt.as<u32>(), d_claim, bs.d_eflag.as<u8>());
+    }
+    // ---- graph
     GCHK(bs.d_link.ensure((size_t)D * 8));
     GCHK(bs.d_clen.ensure((size_t)D * 4));
     GCHK(bs.d_ecid.ensure((size_t)D * 4));
     GCHK(bs.d_ecoff.ensure((size_t)D * 8));
     GCHK(bs.d_seg_cbases.ensure((size_t)S * 8 + (size_t)S * 4));   // u64 bases[S] then u32 counts[S]: one read-back
     u32* d_seg_ncontig = reinterpret_cast<u32*>(bs.d_seg_cbases.as<u64>() + S);
-    // (k_node_flags also initialises link = none and clen = 0 for its edge)
     GraphView gv;
     gv.dk_key = bs.d_dk_key.p;
     gv.dstart = bs.d_dstart.as<u32>();
@@ -430,13 +430,14 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     const u32 dchunks = (u32)ceil_div_u64(maxD, GASM_WG);     // workgroups per segment of the per-edge kernels
     const dim3 grid_seg = seg_grid(dchunks, S);
     const dim3 grid_all(ceil_div_u64(D, GASM_WG));
-    if (W == 1) {
-        GLAUNCH(ctx, "k_node_flags", k_node_flags<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
-        GLAUNCH(ctx, "k_edge_next", k_edge_next<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
-    } else {
-        GLAUNCH(ctx, "k_node_flags", k_node_flags<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
-        GLAUNCH(ctx, "k_edge_next", k_edge_next<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
-    }
+    u32* const d_tgt = bs.d_ecid.as<u32>();        // first out-edge of every edge's target node; e_cid is written later (k_contig_scan)
+    if (W == 1) GLAUNCH(ctx, "k_edge_target", k_edge_target<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim);
+    else GLAUNCH(ctx, "k_edge_target", k_edge_target<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim);
+    GLAUNCH(ctx, "k_edge_multi", k_edge_multi, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim, bs.d_eflag.as<u8>());
+    // (k_node_flags also initialises link = none and clen = 0 for its edge)
+    if (W == 1) GLAUNCH(ctx, "k_node_flags", k_node_flags<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_claim, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
+    else GLAUNCH(ctx, "k_node_flags", k_node_flags<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_claim, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
+    GLAUNCH(ctx, "k_edge_next", k_edge_next, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
     int rounds = 1;
     while ((1ull << rounds) < (u64)maxD) ++rounds;
     rounds += 1;
