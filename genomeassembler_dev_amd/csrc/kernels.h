@@ -88,13 +88,15 @@ __global__ void k_node_flags(GraphView gv, u32 n_segments, u32 chunks, const u32
 __global__ void k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u32* tgt, const u8* eflag, u32* nxt, u64* link);
 __global__ void k_link_jump(GraphView gv, u32 n_segments, u32 chunks, u64* link, const u32* prev_active, u32* active, int jumps);
 __global__ void k_link_rank_seg(GraphView gv, u64* link, int max_rounds);
+__global__ void k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, const u64* link, u32* rtab);
+__global__ void k_rank_lds(GraphView gv, const u32* rtab, u64* link, int max_rounds);
 __global__ void k_chain_len(const u8* eflag, const u32* nxt, const u64* link, u32* clen, u32 n_edges);
 __global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u32* e_cid, u64* e_coff, u32* seg_ncontig,
                               u64* seg_cbases);
 __global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* clen, const u32* seg_cstart,
                                const u64* seg_bstart, u32* e_cid, u64* e_coff, u64* c_off, u32 n_segments, u32 chunks);
 template <class K>
-__global__ void k_contig_emit(GraphView gv, const u8* eflag, const u64* link, const u64* e_coff, u8* out, u32 n_edges);
+__global__ void k_contig_emit(GraphView gv, const u8* eflag, const u64* link, const u64* e_coff, u8* out, u32 n_segments, u32 chunks);
 
 // ---- kernels_score.hip
 struct SeedTable {

@@ -757,6 +757,110 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
     if (open) *active = 1u;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// List ranking through LDS for segments of up to 65534 edges.  Pointer doubling costs ~log2(chain length) scattered
+// reads per edge, and scattered 8-byte reads are bound by the L2 request rate (16 per clock and XCD: ~0.25 ms for
+// 3.8 M edges).  So only every second edge of a segment — the "rulers", even local index — is ranked by doubling, and
+// that happens in LDS:
+//   k_rank_rulers   every ruler walks back along the initial links to the nearest ruler or head (two steps on average)
+//                   and writes one 32-bit entry: ancestor (local index) << 16 | distance;
+//   k_rank_lds      one workgroup per segment doubles the ruler list inside LDS (up to 32767 entries = 128 KB) and
+//                   writes the rulers' final links;
+//   k_link_jump     finishes the odd edges: the ruler behind them is final, so a step or two each.
+// An entry's ancestor is a ruler (even) until the walk or a doubling step reaches a head; heads may be odd or even, an
+// even head's own entry is the self-loop (itself, 0).  So "my ancestor is a head" <=> it is odd or its entry loops.
+// ----------------------------------------------------------------------------------------------------------------
+#define GASM_RANK_NONE 0xFFFFFFFFu
+__global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, const u64* __restrict__ link,
+                                                         u32* __restrict__ rtab) {
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
+    const u32 nb = 1u << gv.bbits;
+    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
+    const u32 r = chunk * GASM_WG + threadIdx.x;      // ruler ordinal inside the segment
+    const u32 i = lo + 2 * r;
+    if (i >= hi) return;
+    u32 cur = i, acc = 0, e = GASM_RANK_NONE;
+    for (int step = 0; step < 512; ++step) {          // the walk ends at the first even edge: 2 steps on average
+        const u64 l = link[cur];
+        const u32 a = (u32)(l >> 32);
+        if (a == GASM_NONE32) break;
+        acc += (u32)l & 0x7FFFFFFFu;
+        const u32 al = a - lo;
+        if ((l & GASM_LINK_DONE) || !(al & 1u)) { e = (al << 16) | acc; break; }
+        cur = a;
+    }
+    rtab[(lo >> 1) + seg + r] = e;                    // segment s owns entries [(lo >> 1) + s, ...): room for the odd ends
+}
+
+__global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __restrict__ rtab, u64* __restrict__ link, int max_rounds) {
+    extern __shared__ u32 s_e[];
+    __shared__ u32 s_active;
+    const u32 seg = blockIdx.x;
+    const u32 nb = 1u << gv.bbits;
+    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
+    const u32 nr = (hi - lo + 1) >> 1;
+    const u32* src = rtab + (lo >> 1) + seg;
+    // a thread owns entries threadIdx.x + 1024 q and keeps them in registers: a doubling step is then one LDS gather
+    // (the ancestor's entry) and one LDS write (so that others see the progress) — the kernel is bound by LDS operations
+    u32 mine[32];
+    u32 done = 0;                                     // bit q: entry q of this thread is final (or dead)
+#pragma unroll
+    for (u32 q = 0; q < 32; ++q) {
+        const u32 r = threadIdx.x + 1024 * q;
+        mine[q] = r < nr ? src[r] : GASM_RANK_NONE;
+        if (r < nr) s_e[r] = mine[q];
+        // dead, or the ancestor is an odd head: final from the start
+        if (mine[q] == GASM_RANK_NONE || ((mine[q] >> 16) & 1u)) done |= 1u << q;
+    }
+    for (int round = 0; round < max_rounds; ++round) {
+        if (threadIdx.x == 0) s_active = 0;
+        __syncthreads();
+        bool any = false;
+#pragma unroll
+        for (u32 q0 = 0; q0 < 32; q0 += 8) {
+            if (((done >> q0) & 0xFFu) == 0xFFu) continue;        // nothing open in this batch
+            u32 ea[8];
+#pragma unroll
+            for (u32 u = 0; u < 8; ++u) ea[u] = ((done >> (q0 + u)) & 1u) ? 0u : s_e[mine[q0 + u] >> 17];
+#pragma unroll
+            for (u32 u = 0; u < 8; ++u) {
+                const u32 q = q0 + u;
+                if ((done >> q) & 1u) continue;
+                const u32 r = threadIdx.x + 1024 * q, e = mine[q], a = e >> 16;
+                u32 ne;
+                if (ea[u] == GASM_RANK_NONE) { ne = GASM_RANK_NONE; done |= 1u << q; }
+                else if ((ea[u] >> 16) == a) {                                            // the ancestor is an even head ...
+                    done |= 1u << q;
+                    if (!(ea[u] & 0xFFFFu)) continue;
+                    ne = GASM_RANK_NONE;                                                  // ... or a cycle folded onto itself
+                } else if ((ea[u] >> 16) == 2 * r) { ne = GASM_RANK_NONE; done |= 1u << q; }   // my own cycle
+                else {
+                    ne = (ea[u] & 0xFFFF0000u) | (((e & 0xFFFFu) + (ea[u] & 0xFFFFu)) & 0xFFFFu);
+                    if ((ne >> 16) & 1u) done |= 1u << q;                                 // reached an odd head
+                    else any = true;
+                }
+                mine[q] = ne;
+                s_e[r] = ne;
+            }
+        }
+        if (any) s_active = 1;
+        __syncthreads();
+        const bool go = s_active != 0;
+        __syncthreads();
+        if (!go) break;
+    }
+    // final links of the rulers; what is still open after 2^18 steps' worth of doubling sits on an isolated cycle
+#pragma unroll
+    for (u32 q = 0; q < 32; ++q) {
+        const u32 r = threadIdx.x + 1024 * q;
+        if (r >= nr) continue;
+        const u32 e = mine[q];
+        const bool fin = (done >> q) & 1u;
+        link[lo + 2 * r] = (fin && e != GASM_RANK_NONE) ? (((u64)(lo + (e >> 16)) << 32) | GASM_LINK_DONE | (e & 0xFFFFu)) : ~0ull;
+    }
+}
+
 // All rounds of pointer doubling for one segment inside one workgroup (no launch per round, early exit when every
 // chain has reached its head).  Links are read and written with relaxed workgroup-scope atomics so the
 // updates other waves of this workgroup made in the same round or the previous one are seen (workgroup scope: one
@@ -895,9 +999,13 @@ __global__ void __launch_bounds__(GASM_WG) k_contig_place(GraphView gv, const u8
 // Every edge on a chain writes its last base at head offset + (k-1) + distance; the head also writes its node.
 template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_contig_emit(GraphView gv, const u8* __restrict__ eflag, const u64* __restrict__ link,
-                                                         const u64* __restrict__ e_coff, u8* __restrict__ out, u32 n_edges) {
-    const u32 i = blockIdx.x * GASM_WG + threadIdx.x;
-    if (i >= n_edges) return;
+                                                         const u64* __restrict__ e_coff, u8* __restrict__ out, u32 n_segments,
+                                                         u32 chunks) {
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;       // the byte scatter into a segment's contigs merges in one L2
+    const u32 nb = 1u << gv.bbits;
+    const u32 i = gv.dstart[seg * nb] + chunk * GASM_WG + threadIdx.x;
+    if (i >= gv.dstart[(seg + 1) * nb]) return;
     const u64 l = link[i];
     const u32 a = (u32)(l >> 32);
     if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;
@@ -910,5 +1018,5 @@ __global__ void __launch_bounds__(GASM_WG) k_contig_emit(GraphView gv, const u8*
         for (int j = 0; j < k - 1; ++j) out[off + j] = "ACGT"[klow2(kshr(key, 2 * (k - 1 - j)))];
     }
 }
-template __global__ void k_contig_emit<u64>(GraphView, const u8*, const u64*, const u64*, u8*, u32);
-template __global__ void k_contig_emit<K128>(GraphView, const u8*, const u64*, const u64*, u8*, u32);
+template __global__ void k_contig_emit<u64>(GraphView, const u8*, const u64*, const u64*, u8*, u32, u32);
+template __global__ void k_contig_emit<K128>(GraphView, const u8*, const u64*, const u64*, u8*, u32, u32);

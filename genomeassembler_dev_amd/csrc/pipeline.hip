@@ -441,16 +441,30 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     int rounds = 1;
     while ((1ull << rounds) < (u64)maxD) ++rounds;
     rounds += 1;
-    if (getenv("GASM_RANK_SEG") && maxD <= (1u << 18)) {
-        // (kept for comparison) one workgroup per segment runs every round with early exit
-        GLAUNCH(ctx, "k_link_rank_seg", k_link_rank_seg, dim3(S), dim3(1024), 0, gv, bs.d_link.as<u64>(), rounds + 1);
+    u32* const act = bs.d_flags.as<u32>() + 16;     // "still active" words of the k_link_jump launches, zeroed at the start of the build
+    const u32 jchunks = (u32)ceil_div_u64(maxD, GASM_WG * 4);      // GASM_JUMP_ILP links per thread
+    if (maxD <= 65534 && !getenv("GASM_RANK_GLOBAL")) {
+        // every second edge (the rulers) is ranked inside LDS, the others then need a step or two (kernels_build.hip)
+        const u32 max_rulers = (maxD + 1) / 2, rchunks = (u32)ceil_div_u64(max_rulers, GASM_WG);
+        GCHK(bs.d_rtab.ensure(((size_t)D / 2 + S + 2) * 4));
+        static bool rank_attr_set = false;
+        if (!rank_attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+            rank_attr_set = true;
+        }
+        GLAUNCH(ctx, "k_rank_rulers", k_rank_rulers, seg_grid(rchunks, S), dim3(GASM_WG), 0, gv, S, rchunks, bs.d_link.as<u64>(), bs.d_rtab.as<u32>());
+        GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)max_rulers * 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), getenv("GASM_DBG_RANK_ROUNDS") ? atoi(getenv("GASM_DBG_RANK_ROUNDS")) : 18);
+        // the odd edges: the ruler behind an edge is usually one or two steps away (a longer gap is geometrically rare)
+        // (spans grow by a factor of jumps + 1 per launch at the very least, so four launches cover any segment; all
+        // but the first normally return at once)
+        const int jumps = 32, launches = 4;
+        for (int r = 0; r < launches; ++r)
+            GLAUNCH(ctx, "k_link_jump", k_link_jump, seg_grid(jchunks, S), dim3(GASM_WG), 0, gv, S, jchunks, bs.d_link.as<u64>(), r ? act + r - 1 : nullptr, act + r, jumps);
     } else {
         // whole-GPU launches of `jumps` doubling steps each; a launch returns at once when its predecessor found every chain done
         // (spans grow by at least jumps + 1 = 5 per launch: log2(5) > 2.3 rounds' worth)
         const int jumps = 4, launches = (rounds * 10 + 22) / 23 + 1;
         if (launches > 40) { gasm_set_error("segment too large for the list-ranking flags"); return GASM_ERR_CAPACITY; }
-        u32* act = bs.d_flags.as<u32>() + 16;     // zeroed with the flags at the start of the build
-        const u32 jchunks = (u32)ceil_div_u64(maxD, GASM_WG * 4);      // GASM_JUMP_ILP links per thread
         for (int r = 0; r < launches; ++r)
             GLAUNCH(ctx, "k_link_jump", k_link_jump, seg_grid(jchunks, S), dim3(GASM_WG), 0, gv, S, jchunks, bs.d_link.as<u64>(), r ? act + r - 1 : nullptr, act + r, jumps);
     }
@@ -479,11 +493,11 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, ctx->stream, bs.d_c_off.as<u64>() + bs.n_contigs, bs.contig_bases);
     if (bs.n_contigs) {
         if (W == 1) {
-            GLAUNCH(ctx, "k_contig_emit", k_contig_emit<u64>, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
-                    bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), D);
+            GLAUNCH(ctx, "k_contig_emit", k_contig_emit<u64>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
+                    bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, dchunks);
         } else {
-            GLAUNCH(ctx, "k_contig_emit", k_contig_emit<K128>, grid_all, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
-                    bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), D);
+            GLAUNCH(ctx, "k_contig_emit", k_contig_emit<K128>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
+                    bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, dchunks);
         }
     }
     return GASM_OK;
