@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
         act[q] = (u32)(l[q] >> 32) != GASM_NONE32 && !(l[q] & GASM_LINK_DONE);
     }
     const bool mine = act[0] || act[1] || act[2] || act[3];
-    for (int j = 0; j < jumps; ++j) {
+    for (int j = 0; j < jumps && (act[0] || act[1] || act[2] || act[3]); ++j) {
         u64 la[GASM_JUMP_ILP];
 #pragma unroll
         for (int q = 0; q < GASM_JUMP_ILP; ++q)      // may be stale: fine
@@ -742,7 +742,7 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
 #pragma unroll
         for (int q = 0; q < GASM_JUMP_ILP; ++q) {
             if (!act[q]) continue;
-            if ((u32)(la[q] >> 32) == GASM_NONE32) { act[q] = false; continue; }
+            if ((u32)(la[q] >> 32) == GASM_NONE32) { l[q] = ~0ull; act[q] = false; continue; }   // behind a dropped edge: dropped too
             l[q] = (la[q] & (0xFFFFFFFF00000000ull | GASM_LINK_DONE)) | (u64)(((u32)l[q] + (u32)la[q]) & 0x7FFFFFFFu);
             if (l[q] & GASM_LINK_DONE) act[q] = false;
         }
@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
 #pragma unroll
     for (int q = 0; q < GASM_JUMP_ILP; ++q) {
         const u32 i = i0 + q * GASM_WG;
-        if (i < hi && (u32)(l[q] >> 32) != GASM_NONE32) { link[i] = l[q]; open = open || !(l[q] & GASM_LINK_DONE); }
+        if (i < hi) { link[i] = l[q]; open = open || ((u32)(l[q] >> 32) != GASM_NONE32 && !(l[q] & GASM_LINK_DONE)); }
     }
     if (open) *active = 1u;
 }
@@ -771,6 +771,8 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
 // even head's own entry is the self-loop (itself, 0).  So "my ancestor is a head" <=> it is odd or its entry loops.
 // ----------------------------------------------------------------------------------------------------------------
 #define GASM_RANK_NONE 0xFFFFFFFFu
+#define GASM_RULER_SHIFT 1            // rulers = edges whose local index is a multiple of 1 << GASM_RULER_SHIFT
+#define GASM_RULER_MASK ((1u << GASM_RULER_SHIFT) - 1u)
 __global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, const u64* __restrict__ link,
                                                          u32* __restrict__ rtab) {
     u32 seg, chunk;
@@ -778,7 +780,7 @@ __global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_seg
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
     const u32 r = chunk * GASM_WG + threadIdx.x;      // ruler ordinal inside the segment
-    const u32 i = lo + 2 * r;
+    const u32 i = lo + (r << GASM_RULER_SHIFT);
     if (i >= hi) return;
     u32 cur = i, acc = 0, e = GASM_RANK_NONE;
     for (int step = 0; step < 512; ++step) {          // the walk ends at the first even edge: 2 steps on average
@@ -787,10 +789,10 @@ __global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_seg
         if (a == GASM_NONE32) break;
         acc += (u32)l & 0x7FFFFFFFu;
         const u32 al = a - lo;
-        if ((l & GASM_LINK_DONE) || !(al & 1u)) { e = (al << 16) | acc; break; }
+        if ((l & GASM_LINK_DONE) || !(al & GASM_RULER_MASK)) { e = (al << 16) | acc; break; }
         cur = a;
     }
-    rtab[(lo >> 1) + seg + r] = e;                    // segment s owns entries [(lo >> 1) + s, ...): room for the odd ends
+    rtab[(lo >> GASM_RULER_SHIFT) + seg + r] = e;     // segment s owns entries [(lo >> shift) + s, ...): room for the ragged ends
 }
 
 __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __restrict__ rtab, u64* __restrict__ link, int max_rounds) {
@@ -799,8 +801,8 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
     const u32 seg = blockIdx.x;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 nr = (hi - lo + 1) >> 1;
-    const u32* src = rtab + (lo >> 1) + seg;
+    const u32 nr = (hi - lo + GASM_RULER_MASK) >> GASM_RULER_SHIFT;
+    const u32* src = rtab + (lo >> GASM_RULER_SHIFT) + seg;
     // a thread owns entries threadIdx.x + 1024 q and keeps them in registers: a doubling step is then one LDS gather
     // (the ancestor's entry) and one LDS write (so that others see the progress) — the kernel is bound by LDS operations
     u32 mine[32];
@@ -811,7 +813,7 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
         mine[q] = r < nr ? src[r] : GASM_RANK_NONE;
         if (r < nr) s_e[r] = mine[q];
         // dead, or the ancestor is an odd head: final from the start
-        if (mine[q] == GASM_RANK_NONE || ((mine[q] >> 16) & 1u)) done |= 1u << q;
+        if (mine[q] == GASM_RANK_NONE || ((mine[q] >> 16) & GASM_RULER_MASK)) done |= 1u << q;
     }
     for (int round = 0; round < max_rounds; ++round) {
         if (threadIdx.x == 0) s_active = 0;
@@ -822,7 +824,7 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
             if (((done >> q0) & 0xFFu) == 0xFFu) continue;        // nothing open in this batch
             u32 ea[8];
 #pragma unroll
-            for (u32 u = 0; u < 8; ++u) ea[u] = ((done >> (q0 + u)) & 1u) ? 0u : s_e[mine[q0 + u] >> 17];
+            for (u32 u = 0; u < 8; ++u) ea[u] = ((done >> (q0 + u)) & 1u) ? 0u : s_e[mine[q0 + u] >> (16 + GASM_RULER_SHIFT)];
 #pragma unroll
             for (u32 u = 0; u < 8; ++u) {
                 const u32 q = q0 + u;
@@ -834,10 +836,10 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
                     done |= 1u << q;
                     if (!(ea[u] & 0xFFFFu)) continue;
                     ne = GASM_RANK_NONE;                                                  // ... or a cycle folded onto itself
-                } else if ((ea[u] >> 16) == 2 * r) { ne = GASM_RANK_NONE; done |= 1u << q; }   // my own cycle
+                } else if ((ea[u] >> 16) == (r << GASM_RULER_SHIFT)) { ne = GASM_RANK_NONE; done |= 1u << q; }   // my own cycle
                 else {
                     ne = (ea[u] & 0xFFFF0000u) | (((e & 0xFFFFu) + (ea[u] & 0xFFFFu)) & 0xFFFFu);
-                    if ((ne >> 16) & 1u) done |= 1u << q;                                 // reached an odd head
+                    if ((ne >> 16) & GASM_RULER_MASK) done |= 1u << q;                   // reached a head that is no ruler
                     else any = true;
                 }
                 mine[q] = ne;
@@ -857,7 +859,7 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
         if (r >= nr) continue;
         const u32 e = mine[q];
         const bool fin = (done >> q) & 1u;
-        link[lo + 2 * r] = (fin && e != GASM_RANK_NONE) ? (((u64)(lo + (e >> 16)) << 32) | GASM_LINK_DONE | (e & 0xFFFFu)) : ~0ull;
+        link[lo + (r << GASM_RULER_SHIFT)] = (fin && e != GASM_RANK_NONE) ? (((u64)(lo + (e >> 16)) << 32) | GASM_LINK_DONE | (e & 0xFFFFu)) : ~0ull;
     }
 }
 

@@ -455,9 +455,9 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         GLAUNCH(ctx, "k_rank_rulers", k_rank_rulers, seg_grid(rchunks, S), dim3(GASM_WG), 0, gv, S, rchunks, bs.d_link.as<u64>(), bs.d_rtab.as<u32>());
         GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)max_rulers * 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), getenv("GASM_DBG_RANK_ROUNDS") ? atoi(getenv("GASM_DBG_RANK_ROUNDS")) : 18);
         // the odd edges: the ruler behind an edge is usually one or two steps away (a longer gap is geometrically rare)
-        // (spans grow by a factor of jumps + 1 per launch at the very least, so four launches cover any segment; all
-        // but the first normally return at once)
-        const int jumps = 32, launches = 4;
+        // (a thread stops as soon as its link is final; spans grow by a factor of jumps + 1 per launch at the very
+        // least, so two launches cover any segment of this size, and the second normally returns at once)
+        const int jumps = 255, launches = 2;
         for (int r = 0; r < launches; ++r)
             GLAUNCH(ctx, "k_link_jump", k_link_jump, seg_grid(jchunks, S), dim3(GASM_WG), 0, gv, S, jchunks, bs.d_link.as<u64>(), r ? act + r - 1 : nullptr, act + r, jumps);
     } else {
