@@ -443,8 +443,12 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
         if ((dbg & 3) == 1) { u64 x = 0; for (int q = 0; q < KPL; ++q) x ^= khash(kx[q]); if (x == 0x1234567) s_tmp[6] = 1; continue; }
         if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { s_tmp[5] = 1; break; }
         if constexpr (!WIDE) {
-            // two batches of four keys: the four home sets are read together (8 x ds_read_b128 in flight), hits are
-            // counted, the few keys that are not done loop on their own
+            // two batches of four keys: the four home sets are read together (8 x ds_read_b128 in flight) and hits are
+            // counted.  Keys that miss their home set (new keys, and the ~1.5 % whose home set has overflowed) are only
+            // noted: with 64 lanes some lane misses for almost every key index, and handling misses in place ran the
+            // slow probe loop — a few dependent LDS round trips — eight times per iteration for the whole wave.  They
+            // are worked off afterwards in one loop in which every lane takes its own next missed key.
+            u32 missed = 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 u32 set[4];
@@ -458,16 +462,22 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const u64 key = kx[4 * h + q];
-                    if (kis_filler(key)) continue;
                     const int slot = c01[q].x == key ? 0 : c01[q].y == key ? 1 : c23[q].x == key ? 2 : c23[q].y == key ? 3 : -1;
+                    if (kis_filler(key)) continue;            // (before the slot test: the all-ones filler equals a free slot)
                     if (slot >= 0) atomicAdd(&t_cnt[4 * set[q] + slot], 1u);
-                    else {
-                        u32 st = set[q];
-                        bool ok = false;
-                        for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
-                        if (!ok) s_tmp[5] = 1;
-                    }
+                    else missed |= 1u << (4 * h + q);
                 }
+            }
+            while (missed) {
+                const u32 q = (u32)__builtin_ctz(missed);
+                missed &= missed - 1;
+                u64 key = kx[0];
+#pragma unroll
+                for (u32 e = 1; e < 8; ++e) if (e == q) key = kx[e];
+                u32 st = khash(key) >> (32 - LOG_SETS);
+                bool ok = false;
+                for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
+                if (!ok) s_tmp[5] = 1;
             }
         } else {
             // 128-bit keys: the four home sets' count words and first two slots are read together; anything not a hit in
