@@ -317,10 +317,12 @@ template __global__ void k_bucket_scatter<K128>(ReadSet, const uint4*, int, int,
 // De-duplicate one bucket: stream its keys through an LDS table (count per distinct key), then order the distinct keys
 // and write them and their multiplicities back over the start of the bucket's own range.
 //
-// The table is TBL/4 sets of four slots.  A key lives in the first set with room, counted from its home set; sets fill
-// left to right.  One probe = the whole set, so unless a home set has overflowed (rare at <= 40 % load) a key is found
-// in the first probe — which matters because a wave moves at the pace of its slowest lane: with one-slot probing some
-// lane of 64 always needs a second and third round.
+// The table is made of small sets of slots: two 64-bit keys (one 16-byte LDS read per probe) or four 128-bit keys.  A
+// key lives in the first set with room, counted from its home set; sets fill left to right.  One probe = the whole set,
+// so most keys are found in the first probe; the rest — new keys, and keys whose home set had overflowed — are noted
+// and worked off in one loop per iteration in which every lane takes its own next missed key.  (With 64 lanes some lane
+// misses for almost every key index; handling misses in place ran the slow probe loop for the whole wave each time.)
+// The kernel is LDS-bound — the random 16-byte reads conflict on banks — so a probe reads as few bytes as it can.
 //   64-bit keys : slot claimed by a 64-bit CAS on the key itself (EMPTY -> key);
 //   128-bit keys: no 128-bit CAS in LDS — the slot's count word is the lock: CAS 0 -> LOCKED, write the key, then
 //                 count = 1.  Readers compare keys only in slots whose count says "ready"; a LOCKED slot means "try
@@ -347,40 +349,40 @@ __device__ __forceinline__ uint4 lds_load128u(const void* p) {
 // or a locked slot, next set when this one is full of other keys).
 template <int TBL>
 __device__ __forceinline__ bool dedup_step(u64* t_key, u32* t_cnt, u32* n_distinct, u64 key, u32& set) {
-    constexpr u32 NSETS = TBL / 4;
-    const u64x2 c01 = lds_load128(&t_key[4 * set]);
-    const u64x2 c23 = lds_load128(&t_key[4 * set + 2]);
-    int slot = c01.x == key ? 0 : c01.y == key ? 1 : c23.x == key ? 2 : c23.y == key ? 3 : -1;
+    constexpr u32 NSETS = TBL / 2;                            // 64-bit keys: sets of two = one 16-byte LDS read per probe
+    const u64x2 c = lds_load128(&t_key[2 * set]);
+    int slot = c.x == key ? 0 : c.y == key ? 1 : -1;
     if (slot < 0) {
-        const int emp = c01.x == GASM_EMPTY64 ? 0 : c01.y == GASM_EMPTY64 ? 1 : c23.x == GASM_EMPTY64 ? 2 : c23.y == GASM_EMPTY64 ? 3 : -1;
+        const int emp = c.x == GASM_EMPTY64 ? 0 : c.y == GASM_EMPTY64 ? 1 : -1;
         if (emp < 0) { set = (set + 1) & (NSETS - 1); return false; }
-        const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&t_key[4 * set + emp]), (unsigned long long)GASM_EMPTY64,
+        const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&t_key[2 * set + emp]), (unsigned long long)GASM_EMPTY64,
                                   (unsigned long long)key);
         if (old == GASM_EMPTY64) atomicAdd(n_distinct, 1u);
         else if (old != key) return false;       // someone else took the slot: look at the set again
         slot = emp;
     }
-    atomicAdd(&t_cnt[4 * set + slot], 1u);
+    atomicAdd(&t_cnt[2 * set + slot], 1u);
     return true;
 }
 template <int TBL>
 __device__ __forceinline__ bool dedup_step(K128* t_key, u32* t_cnt, u32* n_distinct, const K128& key, u32& set) {
-    constexpr u32 NSETS = TBL / 4;
-    const uint4 c = lds_load128u(&t_cnt[4 * set]);            // counts first: a ready count guarantees a complete key
-    const u32 cc[4] = {c.x, c.y, c.z, c.w};
+    constexpr u32 NSETS = TBL / 2;
+    __asm__ volatile("" ::: "memory");
+    const uint2 c = *reinterpret_cast<const uint2*>(&t_cnt[2 * set]);   // counts first: a ready count guarantees a complete key
+    const u32 cc[2] = {c.x, c.y};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
         if (cc[q] == GASM_SLOT_LOCKED) return false;          // being written: may be this very key
         if (cc[q] == 0) {
-            if (atomicCAS(&t_cnt[4 * set + q], 0u, GASM_SLOT_LOCKED) != 0u) return false;
-            t_key[4 * set + q] = key;
+            if (atomicCAS(&t_cnt[2 * set + q], 0u, GASM_SLOT_LOCKED) != 0u) return false;
+            t_key[2 * set + q] = key;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __hip_atomic_store(&t_cnt[4 * set + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&t_cnt[2 * set + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             atomicAdd(n_distinct, 1u);
             return true;
         }
-        const u64x2 kq = lds_load128(&t_key[4 * set + q]);
-        if (kq.x == key.hi && kq.y == key.lo) { atomicAdd(&t_cnt[4 * set + q], 1u); return true; }
+        const u64x2 kq = lds_load128(&t_key[2 * set + q]);
+        if (kq.x == key.hi && kq.y == key.lo) { atomicAdd(&t_cnt[2 * set + q], 1u); return true; }
     }
     set = (set + 1) & (NSETS - 1);
     return false;
@@ -394,9 +396,9 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     constexpr int BINS = TBL / 4;
     constexpr int SL = TBL / GASM_WG;
     constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
-    constexpr int LOG_SETS = LOG_TBL - 2;
-    constexpr u32 NSETS = TBL / 4;
     constexpr bool WIDE = sizeof(K) == 16;
+    constexpr int LOG_SETS = LOG_TBL - 1;                     // sets of two slots
+    constexpr u32 NSETS = 1u << LOG_SETS;
     static_assert(TBL == 4096 || TBL == 2048, "table size");
     __shared__ __align__(32) K t_key[TBL];
     __shared__ __align__(16) u32 t_cnt[TBL];
@@ -449,23 +451,21 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
             // slow probe loop — a few dependent LDS round trips — eight times per iteration for the whole wave.  They
             // are worked off afterwards in one loop in which every lane takes its own next missed key.
             u32 missed = 0;
+            {
+                u32 set[8];
+                u64x2 c[8];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                u32 set[4];
-                u64x2 c01[4], c23[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    set[q] = khash(kx[4 * h + q]) >> (32 - LOG_SETS);
-                    c01[q] = lds_load128(&t_key[4 * set[q]]);
-                    c23[q] = lds_load128(&t_key[4 * set[q] + 2]);
+                for (int q = 0; q < 8; ++q) {
+                    set[q] = khash(kx[q]) >> (32 - LOG_SETS);
+                    c[q] = lds_load128(&t_key[2 * set[q]]);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u64 key = kx[4 * h + q];
-                    const int slot = c01[q].x == key ? 0 : c01[q].y == key ? 1 : c23[q].x == key ? 2 : c23[q].y == key ? 3 : -1;
+                for (int q = 0; q < 8; ++q) {
+                    const u64 key = kx[q];
                     if (kis_filler(key)) continue;            // (before the slot test: the all-ones filler equals a free slot)
-                    if (slot >= 0) atomicAdd(&t_cnt[4 * set[q] + slot], 1u);
-                    else missed |= 1u << (4 * h + q);
+                    const int slot = c[q].x == key ? 0 : c[q].y == key ? 1 : -1;
+                    if (slot >= 0) atomicAdd(&t_cnt[2 * set[q] + slot], 1u);
+                    else missed |= 1u << q;
                 }
             }
             while (missed) {
@@ -480,31 +480,39 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
                 if (!ok) s_tmp[5] = 1;
             }
         } else {
-            // 128-bit keys: the four home sets' count words and first two slots are read together; anything not a hit in
-            // those goes through the step function
+            // 128-bit keys: the four home sets' count words and both slots are read together; the misses are worked off
+            // afterwards, every lane on its own next missed key (as above)
             u32 set[4];
-            uint4 cn[4];
+            uint2 cn[4];
             u64x2 k0[4], k1[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 set[q] = khash(kx[q]) >> (32 - LOG_SETS);
-                cn[q] = lds_load128u(&t_cnt[4 * set[q]]);
-                k0[q] = lds_load128(&t_key[4 * set[q]]);
-                k1[q] = lds_load128(&t_key[4 * set[q] + 1]);
+                __asm__ volatile("" ::: "memory");
+                cn[q] = *reinterpret_cast<const uint2*>(&t_cnt[2 * set[q]]);
+                k0[q] = lds_load128(&t_key[2 * set[q]]);
+                k1[q] = lds_load128(&t_key[2 * set[q] + 1]);
             }
+            u32 missed = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const K128 key = kx[q];
                 if (kis_filler(key)) continue;
                 const bool r0 = cn[q].x != 0 && cn[q].x != GASM_SLOT_LOCKED, r1 = cn[q].y != 0 && cn[q].y != GASM_SLOT_LOCKED;
-                if (r0 && k0[q].x == key.hi && k0[q].y == key.lo) atomicAdd(&t_cnt[4 * set[q]], 1u);
-                else if (r0 && r1 && k1[q].x == key.hi && k1[q].y == key.lo) atomicAdd(&t_cnt[4 * set[q] + 1], 1u);
-                else {
-                    u32 st = set[q];
-                    bool ok = false;
-                    for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
-                    if (!ok) s_tmp[5] = 1;
-                }
+                if (r0 && k0[q].x == key.hi && k0[q].y == key.lo) atomicAdd(&t_cnt[2 * set[q]], 1u);
+                else if (r0 && r1 && k1[q].x == key.hi && k1[q].y == key.lo) atomicAdd(&t_cnt[2 * set[q] + 1], 1u);
+                else missed |= 1u << q;
+            }
+            while (missed) {
+                const u32 q = (u32)__builtin_ctz(missed);
+                missed &= missed - 1;
+                K128 key = kx[0];
+#pragma unroll
+                for (u32 e = 1; e < 4; ++e) if (e == q) key = kx[e];
+                u32 st = khash(key) >> (32 - LOG_SETS);
+                bool ok = false;
+                for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
+                if (!ok) s_tmp[5] = 1;
             }
         }
     }
@@ -870,56 +878,6 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
         const u32 e = mine[q];
         const bool fin = (done >> q) & 1u;
         link[lo + (r << GASM_RULER_SHIFT)] = (fin && e != GASM_RANK_NONE) ? (((u64)(lo + (e >> 16)) << 32) | GASM_LINK_DONE | (e & 0xFFFFu)) : ~0ull;
-    }
-}
-
-// All rounds of pointer doubling for one segment inside one workgroup (no launch per round, early exit when every
-// chain has reached its head).  Links are read and written with relaxed workgroup-scope atomics so the
-// updates other waves of this workgroup made in the same round or the previous one are seen (workgroup scope: one
-// workgroup = one CU = one L1); a stale value would still be a valid (ancestor, distance) pair.  Members of isolated cycles never reach a head: they are dropped (ancestor =
-// none) once their distance exceeds the segment's edge count.
-#define GASM_RANK_BATCH 8
-__global__ void __launch_bounds__(1024) k_link_rank_seg(GraphView gv, u64* __restrict__ link, int max_rounds) {
-    __shared__ u32 s_active;
-    const u32 seg = blockIdx.x;
-    const u32 nb = 1u << gv.bbits;
-    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 n = hi - lo;
-    for (int r = 0; r < max_rounds; ++r) {
-        if (threadIdx.x == 0) s_active = 0;
-        __syncthreads();
-        bool any = false;
-        for (u32 base = lo + threadIdx.x; base < hi; base += 1024 * GASM_RANK_BATCH) {
-            u64 l[GASM_RANK_BATCH], la[GASM_RANK_BATCH];
-            bool act[GASM_RANK_BATCH];
-#pragma unroll
-            for (int q = 0; q < GASM_RANK_BATCH; ++q) {
-                const u32 i = base + q * 1024;
-                l[q] = i < hi ? __hip_atomic_load(&link[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : ~0ull;
-            }
-#pragma unroll
-            for (int q = 0; q < GASM_RANK_BATCH; ++q) {
-                const u32 a = (u32)(l[q] >> 32);
-                act[q] = a != GASM_NONE32 && !(l[q] & GASM_LINK_DONE);
-                la[q] = act[q] ? __hip_atomic_load(&link[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
-            }
-#pragma unroll
-            for (int q = 0; q < GASM_RANK_BATCH; ++q) {
-                if (!act[q]) continue;
-                const u32 i = base + q * 1024;
-                const u32 a2 = (u32)(la[q] >> 32);
-                const u32 d = ((u32)l[q] & 0x7FFFFFFFu) + ((u32)la[q] & 0x7FFFFFFFu);
-                u64 nl;
-                if (a2 == GASM_NONE32 || d > n) nl = ~0ull;            // on an isolated cycle
-                else { nl = ((u64)a2 << 32) | (la[q] & GASM_LINK_DONE) | d; any = any || !(la[q] & GASM_LINK_DONE); }
-                __hip_atomic_store(&link[i], nl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        if (any) s_active = 1;
-        __syncthreads();
-        const bool go = s_active != 0;
-        __syncthreads();
-        if (!go) break;
     }
 }
 
