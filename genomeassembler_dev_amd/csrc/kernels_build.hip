@@ -156,10 +156,12 @@ __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 p
     }
 }
 
-// Exclusive scan of n u32 into n+1 outputs of type TO; one workgroup of 1024 threads, running carry.  `tail` (optional):
-// one more word copied to out[n + 1], so that a flag can ride to the host behind the scanned array in a single copy.
+// Exclusive scan of n u32 into n+1 outputs of type TO; one workgroup of 1024 threads, running carry.  `report`
+// (optional, pinned host memory the device can write): every `stride`-th output, count + 1 of them, then the word at
+// `tail` — what the host needs after its wait, without a copy engine in between.
 template <class TO>
-__global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, TO* __restrict__ out, u32 n, const u32* __restrict__ tail) {
+__global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, TO* __restrict__ out, u32 n, const u32* __restrict__ tail,
+                                                    u32* __restrict__ report, u32 stride, u32 count) {
     __shared__ u32 s_tmp[16];
     TO carry = 0;
     for (u32 base = 0; base < n; base += 1024) {
@@ -170,10 +172,51 @@ __global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, 
         if (i < n) out[i] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) { out[n] = carry; if (tail) out[n + 1] = (TO)*tail; }
+    if (threadIdx.x == 0) out[n] = carry;
+    if (report) {
+        __syncthreads();          // the outputs were written by this workgroup
+        for (u32 i = threadIdx.x; i <= count; i += 1024) report[i] = (u32)out[(u64)i * stride];
+        if (threadIdx.x == 0) report[count + 1] = tail ? *tail : 0u;
+    }
 }
-template __global__ void k_scan_excl<u64>(const u32*, u64*, u32, const u32*);
-template __global__ void k_scan_excl<u32>(const u32*, u32*, u32, const u32*);
+template __global__ void k_scan_excl<u64>(const u32*, u64*, u32, const u32*, u32*, u32, u32);
+template __global__ void k_scan_excl<u32>(const u32*, u32*, u32, const u32*, u32*, u32, u32);
+
+// Exclusive scans of the per-segment contig counts and bases (k_contig_scan) into the segment directories, on the
+// device and, for the host, in pinned memory: [0, S] contig starts, then [S + 1, 2S + 1] base starts as (lo, hi) pairs.
+__global__ void __launch_bounds__(64) k_seg_offsets(const u32* __restrict__ seg_ncontig, const u64* __restrict__ seg_cbases, u32 S,
+                                                    u32* __restrict__ seg_cstart, u64* __restrict__ seg_bstart, u32* __restrict__ report) {
+    // one wave, 64 segments at a time (a batch rarely has more than a few hundred segments)
+    const u32 ln = threadIdx.x;
+    u32 ccarry = 0;
+    u64 bcarry = 0;
+    for (u32 base = 0; base < S; base += 64) {
+        const u32 i = base + ln;
+        const u32 c = i < S ? seg_ncontig[i] : 0u;
+        const u64 b = i < S ? seg_cbases[i] : 0ull;
+        const u32 cinc = wave_incl_scan(c);
+        u64 binc = b;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 o = __shfl_up(binc, d, 64);
+            if ((int)ln >= d) binc += o;
+        }
+        if (i < S) {
+            const u32 cs = ccarry + cinc - c;
+            const u64 bs = bcarry + binc - b;
+            seg_cstart[i] = cs; seg_bstart[i] = bs;
+            report[i] = cs;
+            report[S + 1 + 2 * i] = (u32)bs; report[S + 2 + 2 * i] = (u32)(bs >> 32);
+        }
+        ccarry += wave_last(cinc);
+        bcarry += __shfl(binc, 63, 64);
+    }
+    if (ln == 0) {
+        seg_cstart[S] = ccarry; seg_bstart[S] = bcarry;
+        report[S] = ccarry;
+        report[S + 1 + 2 * S] = (u32)bcarry; report[S + 2 + 2 * S] = (u32)(bcarry >> 32);
+    }
+}
 
 // ================================================================================================================
 // Scatter the k-mers of every tile into their (segment, bucket) ranges — whole cache lines only.

@@ -331,7 +331,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         }
         GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(1024), 0, rs, bbits, padm, bs.d_cube.as<u16>(),
                 bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
-        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr);
+        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr, (u32*)nullptr, 0u, 0u);
         const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 12 + 64;   // KeyTraits<K>::NFL passes + trash slots
         // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
         const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 8));
@@ -356,7 +356,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         }
         bs.fbits = small_tbl ? 9 : 10;   // bins of the de-duplication kernel's counting sort = TBL / 4
         GCHK(bs.d_fdir.ensure((size_t)nbt * ((1u << bs.fbits) + 1) * 2));
-        HIPCHK(hipMemsetAsync(bs.d_fdir.p, 0, (size_t)nbt * ((1u << bs.fbits) + 1) * 2, ctx->stream));
+        // (k_bucket_dedup writes every entry of its bucket's fine directory)
         if (W == 2) {
             GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<K128, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
                     bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
@@ -376,15 +376,15 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
             fprintf(stderr, "[dedup stamps, 100 MHz ticks per workgroup] init %.1f  first-iter %.1f  stream %.1f  barrier %.1f  order %.1f  writeback %.1f\n",
                     (double)h[0] / nbt, (double)h[1] / nbt, (double)h[2] / nbt, (double)h[3] / nbt, (double)h[4] / nbt, (double)h[5] / nbt);
         }
-        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt, bs.d_flags.as<u32>());
-        bs.h_dstart.resize((size_t)nbt + 1);
-        u32 hflags[2] = {0, 0};
-        // the overflow flag rides behind the directory so one copy + one wait fetches both
-        bs.h_dstart.resize((size_t)nbt + 2);
-        GCHK(d2h_sync(ctx, bs.h_dstart.data(), bs.d_dstart.p, ((size_t)nbt + 2) * 4));
-        hflags[0] = bs.h_dstart[(size_t)nbt + 1];
-        bs.h_dstart.resize((size_t)nbt + 1);
-        if (!hflags[0]) break;
+        // the scan reports the segments' first entries and the overflow flag straight into pinned host memory: one wait,
+        // no copy engine
+        if ((size_t)S + 2 > ctx->h_pin_words * 2) { gasm_set_error("too many segments for the report buffer"); return GASM_ERR_CAPACITY; }
+        u32* const h_rep = reinterpret_cast<u32*>(ctx->h_pin);
+        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt, bs.d_flags.as<u32>(),
+                h_rep, nb, S);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        bs.h_dstart.assign(h_rep, h_rep + S + 1);       // first distinct k-mer of every segment (+ the total)
+        if (!h_rep[S + 1]) break;
         if (small_tbl && W == 1) { small_tbl = false; continue; }   // same partition, larger tables
         if (bbits >= bb_cap) {
             gasm_set_error("a k-mer bucket holds more than %d distinct k-mers even with %d bucket bits", GASM_TBL_LIMIT, bbits);
@@ -394,10 +394,10 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     }
     bs.bbits = bbits;
     const u32 nb = 1u << bbits;
-    const u32 D = bs.h_dstart[nbt];
+    const u32 D = bs.h_dstart[S];
     bs.d_total = D;
     u32 maxD = 0;
-    for (u32 s = 0; s < S; ++s) maxD = std::max(maxD, bs.h_dstart[(size_t)(s + 1) * nb] - bs.h_dstart[(size_t)s * nb]);
+    for (u32 s = 0; s < S; ++s) maxD = std::max(maxD, bs.h_dstart[s + 1] - bs.h_dstart[s]);
     bs.h_seg_cstart.assign((size_t)S + 1, 0);
     bs.h_seg_bstart.assign((size_t)S + 1, 0);
     if (D == 0) return GASM_OK;
@@ -472,18 +472,23 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
             bs.d_clen.as<u32>(), D);
     GLAUNCH(ctx, "k_contig_scan", k_contig_scan, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
             bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), d_seg_ncontig, bs.d_seg_cbases.as<u64>());
-    std::vector<u64> h_cbnc((size_t)S + (S + 1) / 2);
-    GCHK(d2h_sync(ctx, h_cbnc.data(), bs.d_seg_cbases.p, (size_t)S * 12));
-    const u32* h_nc = reinterpret_cast<const u32*>(h_cbnc.data() + S);
-    for (u32 s = 0; s < S; ++s) {
-        bs.h_seg_cstart[s + 1] = bs.h_seg_cstart[s] + h_nc[s];
-        bs.h_seg_bstart[s + 1] = bs.h_seg_bstart[s] + h_cbnc[s];
+    // segment directories of the contigs: scanned on the device, reported through pinned host memory (one wait, no copies)
+    if (3 * (size_t)S + 3 > ctx->h_pin_words * 2) { gasm_set_error("too many segments for the report buffer"); return GASM_ERR_CAPACITY; }
+    GCHK(bs.d_seg_cstart.ensure(((size_t)S + 1) * 4));
+    GCHK(bs.d_seg_bstart.ensure(((size_t)S + 1) * 8));
+    {
+        u32* const h_rep = reinterpret_cast<u32*>(ctx->h_pin);
+        GLAUNCH(ctx, "k_seg_offsets", k_seg_offsets, dim3(1), dim3(64), 0, d_seg_ncontig, bs.d_seg_cbases.as<u64>(), S, bs.d_seg_cstart.as<u32>(),
+                bs.d_seg_bstart.as<u64>(), h_rep);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (u32 s = 0; s <= S; ++s) {
+            bs.h_seg_cstart[s] = h_rep[s];
+            bs.h_seg_bstart[s] = (u64)h_rep[S + 1 + 2 * s] | ((u64)h_rep[S + 2 + 2 * s] << 32);
+        }
     }
     bs.n_contigs = bs.h_seg_cstart[S];
     bs.contig_bases = bs.h_seg_bstart[S];
     if (bs.contig_bases >= 0xFFFFFFF0ull) { gasm_set_error("contigs exceed 2^32 bases"); return GASM_ERR_CAPACITY; }
-    GCHK(h2d(ctx, bs.d_seg_cstart, bs.h_seg_cstart.data(), ((size_t)S + 1) * 4));
-    GCHK(h2d(ctx, bs.d_seg_bstart, bs.h_seg_bstart.data(), ((size_t)S + 1) * 8));
     GCHK(bs.d_c_off.ensure(((size_t)bs.n_contigs + 1) * 8));
     GCHK(bs.d_contig_ascii.ensure(bs.contig_bases + 64));
     if (bs.n_contigs) {
@@ -507,7 +512,7 @@ int pipeline_fetch_distinct(gasm_ctx* ctx, const DevReads& rd, BuildState& bs) {
     if (bs.fetched_distinct) return GASM_OK;
     const u32 S = rd.n_segments, nb = 1u << bs.bbits;
     bs.h_seg_doff.resize((size_t)S + 1);
-    for (u32 s = 0; s <= S; ++s) bs.h_seg_doff[s] = bs.h_dstart.empty() ? 0 : bs.h_dstart[(size_t)s * nb];
+    for (u32 s = 0; s <= S; ++s) bs.h_seg_doff[s] = bs.h_dstart.empty() ? 0 : bs.h_dstart[s];
     bs.h_dk_key.resize((size_t)bs.d_total * bs.words);     // 128-bit keys come back as (hi, lo) pairs
     bs.h_dk_cnt.resize(bs.d_total);
     if (bs.d_total) {
