@@ -108,19 +108,26 @@ __global__ void __launch_bounds__(GASM_TILE_WG) k_tile_hist(ReadSet rs, const ui
     const u32 nb = 1u << bbits;
     for (u32 e = threadIdx.x; e < nb; e += GASM_TILE_WG) s_h[e] = 0;
     __syncthreads();
-    for (u32 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const TileInfo ti = tile_decode(tinfo, tile);
-        Roll<K> r;
-        u32 nv;
-        tile_fetch<K>(rs, ti, g, k, r, nv);
+    // the next tile's words are requested before this tile's atomics (one tile of load latency hidden per tile)
+    u32 tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    Roll<K> r;
+    u32 nv;
+    tile_fetch<K>(rs, tile_decode(tinfo, tile), g, k, r, nv);
+    for (;;) {
         const auto w = r.prep();
+        const u32 nv_now = nv;
+        const u32 tnext = tile + gridDim.x;
+        if (tnext < n_tiles) tile_fetch<K>(rs, tile_decode(tinfo, tnext), g, k, r, nv);
         static_for<KT>([&](auto J) {
             constexpr u32 j = J;
-            if (j < nv) atomicAdd(&s_h[bbits ? w.template top_hi<j>() >> (32 - bbits) : 0u], 1u);
+            if (j < nv_now) atomicAdd(&s_h[bbits ? w.template top_hi<j>() >> (32 - bbits) : 0u], 1u);
         });
         __syncthreads();
         for (u32 e = threadIdx.x; e < nb; e += GASM_TILE_WG) { tcnt[(u64)tile * nb + e] = (u16)s_h[e]; s_h[e] = 0; }
         __syncthreads();
+        if (tnext >= n_tiles) break;
+        tile = tnext;
     }
 }
 template __global__ void k_tile_hist<u64>(ReadSet, const uint4*, int, int, u32, u32, u16*);

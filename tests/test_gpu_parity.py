@@ -190,6 +190,43 @@ def test_batch_ragged_reads_and_empty_segment():
     b.close()
 
 
+def test_large_segment_long_reads_and_cycles(qtable):
+    """(a) a segment with more than 65534 distinct k-mers: list ranking takes the whole-GPU doubling path instead of the
+    LDS one, and the bucket count goes past 64; (b) reads of more than 8192 k-mers: several offset rounds (tiles) per
+    read; (c) a circular sequence: an isolated cycle of edges, which the reference's walk never enters (no contig)."""
+    keys, prob = qtable
+    # (a)
+    g = synth.make_segment(91, 90000, planted=False)
+    reads = synth.simulate_reads(g, 120, 12, 92)
+    rs = _strs(reads)
+    k = 27
+    ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+    b = ga.SegmentBatch(reads.reshape(-1), np.array([0, reads.shape[0]], dtype=np.uint64), fixed_len=120)
+    b.build(k, genome_len_hint=90000).score(8, prob)
+    assert len(ref["distinct"]) > 65534
+    assert b.contigs(0) == ref["contigs"]
+    dk, dm = b.distinct_kmers(0)
+    assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist()
+    o = orc.calc_breakscore(ref["contigs"], rs, "", 8, keys, prob, with_lev=False, with_freq=False)
+    _check_scores({kk: v for kk, v in b.scores().items() if kk != "seg_contig_off"}, o, with_lev=False)
+    b.close()
+    # (b) + (c): two very long reads, short reads, and a 400-base circle read round and round
+    g2 = _strs(synth.make_segment(93, 30000, planted=False)[None, :])[0]
+    circ = _strs(synth.make_segment(94, 400, planted=False)[None, :])[0]
+    long_reads = [g2[100:100 + 9000], g2[4000:4000 + 17001], (circ * 3)[:1000]]
+    short = [g2[i:i + 80] for i in range(0, 29900, 37)]
+    for k in (21, 33):
+        segs = [long_reads + short, [(circ * 4)[i:i + 150] for i in range(0, 800, 7)]]
+        b = ga.SegmentBatch.from_strings(segs)
+        b.build(k)
+        for s, rs2 in enumerate(segs):
+            ref = orc.get_contigs(orc.kmers_from_reads(rs2, k), k, 1, rows=1)
+            assert b.contigs(s) == ref["contigs"], (k, s)
+            dk, dm = b.distinct_kmers(s)
+            assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist(), (k, s)
+        b.close()
+
+
 # ------------------------------------------------------------------------------------------------ calc_breakscore
 def _score_case(seed, L=1200, rl=20, cov=40, k=15):
     g = synth.make_segment(seed, L, n_short=3, short_len=60, n_long=1, long_len=150, tandem_len=60, planted=True)
