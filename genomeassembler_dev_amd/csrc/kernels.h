@@ -62,6 +62,7 @@ struct PathSet {
 };
 
 #define GASM_KT 16          // k-mers per thread and round of the tile kernels for 64-bit keys (8 for 128-bit keys)
+#define GASM_SCORE_PATH_CAP 6144   // paths of one segment whose score accumulators k_score_reads_graph keeps in LDS
 #define GASM_TBL 4096       // slots of the large LDS de-duplication table (the small one has 2048)
 #define GASM_TBL_LIMIT 2816 // distinct keys one bucket may hold (11/16 of the table) before the host re-partitions
 
@@ -108,7 +109,7 @@ __global__ void k_seed_insert(PathSet ps, SeedTable st, const u64* seg_base_off,
 __global__ void k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, u32* poscnt);
 template <class K>
 __global__ void k_score_reads_graph(ReadSet rs, GraphView gv, const u64* link, const u32* e_cid, PathSet ps, const long long* dfix,
-                                    int kmer, u32 reads_per_wg, u32 chunks, u32* cnt, unsigned long long* sum);
+                                    int kmer, u32 reads_per_wg, u32 chunks, u32 lds_paths, u32* cnt, unsigned long long* sum);
 __global__ void k_score_finish(PathSet ps, const u32* cnt, const unsigned long long* sum, const long long* dfix, const u64* seg_empty,
                                int kmer, double inv_scale, double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,
                                int32_t* seq_len, u32 n_paths);

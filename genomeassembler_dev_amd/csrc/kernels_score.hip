@@ -122,11 +122,22 @@ __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& g
     *path = c;
     const u64 g = ps.p_off[c] + ((u32)l & 0x7FFFFFFFu);
     if (g + len > ps.p_off[c + 1]) return ~0ull;
+    // 128 bases per round: five words from either stream (independent loads; both streams end in four padding words),
+    // aligned in registers.  Word-by-word with an early exit was a chain of dependent round trips per read.
     bool same = true;
-    for (u32 o = 0; o < len && same; o += 32) {
-        const u32 nbase = len - o < 32 ? len - o : 32;
-        const u64 x = window32(rs.words, p0 + o), y = window32(ps.words, g + o);
-        same = ((x ^ y) >> (64 - 2 * nbase)) == 0;
+    for (u32 o = 0; o < len && same; o += 128) {
+        const u64 ra = (p0 + o) >> 5, ca = (g + o) >> 5;
+        const u32 sr = (u32)((p0 + o) & 31) << 1, sc = (u32)((g + o) & 31) << 1;
+        u64 rw[5], cw[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { rw[i] = rs.words[ra + i]; cw[i] = ps.words[ca + i]; }
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            if (o + 32 * j >= len) break;
+            const u32 left = len - o - 32 * j, nbase = left < 32 ? left : 32;
+            const u64 x = funnel64(rw[j], rw[j + 1], sr), y = funnel64(cw[j], cw[j + 1], sc);
+            same = same && ((x ^ y) >> (64 - 2 * nbase)) == 0;
+        }
     }
     return same ? g : ~0ull;
 }
@@ -138,14 +149,15 @@ __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& g
 // fixed reduction tree).  A workgroup keeps the accumulators of its segment's paths in LDS (ds_add_u32 / ds_add_u64) and
 // flushes the non-zero ones with global atomics at the end; segments with more paths than fit go to global atomics
 // directly.  A workgroup = one slice of one segment's reads (seg_chunk, device_utils.h).
-#define GASM_SCORE_PATH_CAP 6144
 template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, GraphView gv, const u64* __restrict__ link,
                                                                const u32* __restrict__ e_cid, PathSet ps,
                                                                const long long* __restrict__ dfix, int kmer, u32 reads_per_wg, u32 chunks,
-                                                               u32* __restrict__ cnt, unsigned long long* __restrict__ sum) {
-    __shared__ unsigned long long s_sum[GASM_SCORE_PATH_CAP];
-    __shared__ u32 s_cnt[GASM_SCORE_PATH_CAP];
+                                                               u32 lds_paths, u32* __restrict__ cnt, unsigned long long* __restrict__ sum) {
+    // accumulators of the segment's paths: `lds_paths` (<= GASM_SCORE_PATH_CAP) of each, sized by the launch — a fixed
+    // 72 KB would leave two workgroups per CU, and this kernel is a chain of dependent gathers that lives on occupancy
+    extern __shared__ unsigned long long s_sum[];
+    u32* s_cnt = reinterpret_cast<u32*>(s_sum + lds_paths);
     u32 seg, chunk;
     if (!seg_chunk(rs.n_segments, chunks, &seg, &chunk)) return;      // a segment's graph and contigs stay in one XCD's L2
     const u64 r0 = rs.seg_read_off[seg] + (u64)chunk * reads_per_wg;
@@ -153,7 +165,7 @@ __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, Graph
     if (r0 >= rseg_end) return;
     const u64 r1 = r0 + reads_per_wg < rseg_end ? r0 + reads_per_wg : rseg_end;
     const u32 pfirst = ps.seg_path_off[seg], np = ps.seg_path_off[seg + 1] - pfirst;
-    const bool in_lds = np <= GASM_SCORE_PATH_CAP;
+    const bool in_lds = np <= lds_paths;
     if (in_lds) for (u32 i = threadIdx.x; i < np; i += GASM_WG) { s_sum[i] = 0; s_cnt[i] = 0; }
     __syncthreads();
     for (u64 r = r0 + threadIdx.x; r < r1; r += GASM_WG) {
@@ -175,9 +187,9 @@ __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, Graph
     }
 }
 
-template __global__ void k_score_reads_graph<u64>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32, u32*,
+template __global__ void k_score_reads_graph<u64>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32, u32, u32*,
                                                   unsigned long long*);
-template __global__ void k_score_reads_graph<K128>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32, u32*,
+template __global__ void k_score_reads_graph<K128>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32, u32, u32*,
                                                    unsigned long long*);
 
 // Fixed-point sums -> the reference's per-path numbers.  `seg_empty`: empty reads of the path's segment, each a hit at

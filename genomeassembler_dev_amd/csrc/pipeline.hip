@@ -681,13 +681,22 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
         GCHK(const_cast<ScoreTable&>(tb).set_fixed(ctx, max_reads));
         const u32 reads_per_wg = 256;     // one read per thread: the match is a chain of dependent loads
         const u32 rchunks = (u32)ceil_div_u64(max_reads, reads_per_wg);
+        u32 max_paths = 0;
+        for (u32 s = 0; s < S; ++s) max_paths = std::max(max_paths, dp.h_seg_path_off[s + 1] - dp.h_seg_path_off[s]);
+        const u32 lds_paths = std::min<u32>(std::max(max_paths, 1u), GASM_SCORE_PATH_CAP);   // per-path accumulators kept in LDS
+        static bool score_attr_set = false;
+        if (!score_attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_reads_graph<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, GASM_SCORE_PATH_CAP * 12));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_reads_graph<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, GASM_SCORE_PATH_CAP * 12));
+            score_attr_set = true;
+        }
         if (graph->words == 1) {
-            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<u64>, seg_grid(rchunks, S), dim3(GASM_WG), 0, rd.view(),
-                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, ss.d_total.as<u32>(),
+            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<u64>, seg_grid(rchunks, S), dim3(GASM_WG), (size_t)lds_paths * 12, rd.view(),
+                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, lds_paths, ss.d_total.as<u32>(),
                     d_fx);
         } else {
-            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<K128>, seg_grid(rchunks, S), dim3(GASM_WG), 0, rd.view(),
-                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, ss.d_total.as<u32>(),
+            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<K128>, seg_grid(rchunks, S), dim3(GASM_WG), (size_t)lds_paths * 12, rd.view(),
+                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, lds_paths, ss.d_total.as<u32>(),
                     d_fx);
         }
     } else if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
