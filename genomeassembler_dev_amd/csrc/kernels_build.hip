@@ -260,8 +260,9 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
                                                                   const u16* __restrict__ tcnt, K* __restrict__ keys, u64 scratch) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     constexpr u32 KT = KeyTraits<K>::KT;
-    constexpr u32 NFL = KeyTraits<K>::NFL;               // flush passes: KT + room for the padding
-    constexpr u32 CAP = NFL * GASM_TILE_WG;
+    constexpr u32 NFL = KeyTraits<K>::NFL;               // flush passes of 16 bytes per thread: the tile + room for the padding
+    constexpr u32 KPU = 16 / sizeof(K);                  // keys per 16-byte unit
+    constexpr u32 CAP = NFL * GASM_TILE_WG * KPU;
     const u32 nb = 1u << bbits;
     const u32 tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
     K* s_key = reinterpret_cast<K*>(s_raw);                                  // CAP + one trash slot per thread
@@ -276,7 +277,7 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
     const u32 tile_end = min(n_tiles, (blockIdx.x + 1) * per_wg);
     u32 tile = blockIdx.x * per_wg;
     if (tile >= tile_end) return;
-    const u64 my_scratch = scratch + (u64)(((blockIdx.x & 1023u) * (GASM_TILE_WG / 64) + wv) * 64 + ln);
+    const u64 my_scratch = scratch + (u64)(((blockIdx.x & 1023u) * (GASM_TILE_WG / 64) + wv) * 64 + ln) * KPU;
 
     auto fetch = [&](u32 t, const TileInfo& ti, TilePrefetch<K>& pf) {
         pf.cnt = 0; pf.toff = 0; pf.bs_lo = 0; pf.bs_hi = 0;
@@ -338,20 +339,28 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
 #pragma unroll
         for (u32 j = 0; j < KT; ++j) s_key[j < nv ? idx[j] : CAP + tid] = key[j];
         __syncthreads();
-        // ---- stream out: NFL stores per thread, three keys at a time (their LDS reads overlap)
+        // ---- stream out: NFL 16-byte stores per thread (a pair of 64-bit keys or one 128-bit key; staged runs are even,
+        // so a pair never straddles two buckets), three at a time so that their LDS reads overlap
         static_assert(NFL % 3 == 0, "flush passes come in threes");
 #pragma unroll
         for (u32 u0 = 0; u0 < NFL; u0 += 3) {
-            K kk[3];
+            u64x2 w[3];
             u64 cb[3];
 #pragma unroll
-            for (u32 u = 0; u < 3; ++u) kk[u] = s_key[tid + GASM_TILE_WG * (u0 + u)];
-#pragma unroll
-            for (u32 u = 0; u < 3; ++u) cb[u] = s_comb[bbits ? (kfield(kk[u], bshift) & (nb - 1)) : 0u];
+            for (u32 u = 0; u < 3; ++u) w[u] = *reinterpret_cast<const u64x2*>(s_key + (tid + GASM_TILE_WG * (u0 + u)) * KPU);
 #pragma unroll
             for (u32 u = 0; u < 3; ++u) {
-                const u32 i = tid + GASM_TILE_WG * (u0 + u);
-                keys[i < total ? cb[u] + i : my_scratch] = kk[u];      // (no branch: the number of stores must not vary)
+                u32 bkt = 0;
+                if (bbits) {
+                    if constexpr (KPU == 2) bkt = (u32)(w[u].x >> bshift) & (nb - 1);
+                    else bkt = kfield(K128{w[u].x, w[u].y}, bshift) & (nb - 1);
+                }
+                cb[u] = s_comb[bkt];
+            }
+#pragma unroll
+            for (u32 u = 0; u < 3; ++u) {
+                const u32 i = (tid + GASM_TILE_WG * (u0 + u)) * KPU;
+                *reinterpret_cast<u64x2*>(keys + (i < total ? cb[u] + i : my_scratch)) = w[u];   // (no branch: the number of stores must not vary)
             }
         }
         if (++tile >= tile_end) break;

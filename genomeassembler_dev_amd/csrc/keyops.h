@@ -144,6 +144,6 @@ template <> struct Roll<K128> {
 
 // words per key and k-mers per thread and round of the tile kernels (LDS staging is 8 KB per wave either way)
 template <class K> struct KeyTraits;
-// NFL: store passes of k_bucket_scatter's flush = KT + room for the padding of the staged runs (72 KB of LDS either way)
-template <> struct KeyTraits<u64> { static constexpr int WORDS = 1; static constexpr int KT = 16; static constexpr int NFL = 18; };
+// NFL: 16-byte store passes of k_bucket_scatter's flush = the tile + room for the padding of the staged runs (72 KB of LDS)
+template <> struct KeyTraits<u64> { static constexpr int WORDS = 1; static constexpr int KT = 16; static constexpr int NFL = 9; };
 template <> struct KeyTraits<K128> { static constexpr int WORDS = 2; static constexpr int KT = 8; static constexpr int NFL = 9; };

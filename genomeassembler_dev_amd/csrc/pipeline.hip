@@ -306,7 +306,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     };
     const ReadSet rs = rd.view();
     const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * 8);
-    constexpr u32 SCRATCH_KEYS = 1024 * (GASM_TILE_WG / 64) * 64;   // a line-set per wave of 1024 workgroup slots (k_bucket_scatter)
+    constexpr u32 SCRATCH_KEYS = 1024 * (GASM_TILE_WG / 64) * 64 * 2;   // 16 bytes per lane and wave of 1024 workgroup slots (k_bucket_scatter)
     u32 nbt = 0;
     while (true) {
         const u32 nb = 1u << bbits, padm = pad_mask(nb);
