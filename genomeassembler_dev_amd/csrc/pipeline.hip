@@ -21,6 +21,27 @@ __global__ void k_add_empty_reads(PathSet ps, const u64* __restrict__ seg_empty,
     else total[p] += e;   // an empty path has no position counter: carried as an extra addend
 }
 
+// Tuning / diagnostic knobs, read from the environment once (none changes results except GASM_DBG_DEDUP, an ablation):
+//   GASM_DEDUP_TBL=2048|4096   force the de-duplication table size        GASM_SCATTER_WGS=n   scatter workgroups per CU (8)
+//   GASM_DBG_PADM=m            cap the run padding at m + 1 keys          GASM_RANK_GLOBAL=1   whole-GPU list ranking only
+//   GASM_DBG_RANK_ROUNDS=n     cap the LDS ranking rounds (ablation)      GASM_DBG_DEDUP=1|2   loads only / no ordering (ablation)
+//   GASM_DBG_STAMPS=file       per-phase clock stamps of k_bucket_dedup to stderr and `file`
+struct Knobs {
+    int dedup_tbl = 0, dbg_dedup = 0, padm = -1, scatter_wgs = 8, rank_rounds = 18;
+    bool rank_global = false;
+    const char* stamps = nullptr;
+    Knobs() {
+        if (const char* v = getenv("GASM_DEDUP_TBL")) dedup_tbl = atoi(v);
+        if (const char* v = getenv("GASM_DBG_DEDUP")) dbg_dedup = atoi(v);
+        if (const char* v = getenv("GASM_DBG_PADM")) padm = atoi(v);
+        if (const char* v = getenv("GASM_SCATTER_WGS")) scatter_wgs = std::max(1, atoi(v));
+        if (const char* v = getenv("GASM_DBG_RANK_ROUNDS")) rank_rounds = atoi(v);
+        rank_global = getenv("GASM_RANK_GLOBAL") != nullptr;
+        stamps = getenv("GASM_DBG_STAMPS");
+    }
+};
+static const Knobs& knobs() { static const Knobs k; return k; }
+
 // grid of the segment-major kernels (seg_chunk, device_utils.h): 8 x chunks x ceil(S / 8) workgroups
 static dim3 seg_grid(u32 chunks, u32 S) { return dim3(8u * chunks * ((S + 7u) / 8u)); }
 
@@ -274,10 +295,10 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     {
         const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
         small_tbl = (dest >> bbits) <= 900;   // else the 4096-slot table (fewer workgroups per CU)
-        if (getenv("GASM_DEDUP_TBL")) small_tbl = atoi(getenv("GASM_DEDUP_TBL")) == 2048;
+        if (knobs().dedup_tbl) small_tbl = knobs().dedup_tbl == 2048;
         if (W == 2) small_tbl = true;         // 128-bit keys: 2048-slot tables only
     }
-    const int dbg_d = getenv("GASM_DBG_DEDUP") ? atoi(getenv("GASM_DBG_DEDUP")) : 0;
+    const int dbg_d = knobs().dbg_dedup;
     static bool lds_attr_set = false;
     if (!lds_attr_set) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -300,7 +321,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     const u32 line_keys = 128 / KB, pad_room = W == 1 ? 2 * GASM_TILE_WG : GASM_TILE_WG;
     auto pad_mask = [&](u32 nb) {
         u32 m = line_keys - 1;
-        if (getenv("GASM_DBG_PADM")) m = std::min<u32>(m, (u32)atoi(getenv("GASM_DBG_PADM")));   // tuning
+        if (knobs().padm >= 0) m = std::min<u32>(m, (u32)knobs().padm);
         while (m && (u64)nb * m > pad_room) m >>= 1;
         return m;
     };
@@ -334,7 +355,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr, (u32*)nullptr, 0u, 0u);
         const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 12 + 64;   // KeyTraits<K>::NFL passes + trash slots
         // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
-        const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (getenv("GASM_SCATTER_WGS") ? atoi(getenv("GASM_SCATTER_WGS")) : 8));
+        const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
         if (W == 1) {
             GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
                     bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), n_alloc);
@@ -344,7 +365,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         }
         unsigned long long* d_stamps = nullptr;
         static DBuf stamp_buf;
-        if (getenv("GASM_DBG_STAMPS")) {   // diagnostic: per-phase cycle totals of k_bucket_dedup to stderr
+        if (knobs().stamps) {   // diagnostic: per-phase cycle totals of k_bucket_dedup to stderr
             int o1 = 0, o2 = 0, o3 = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_bucket_dedup<u64, 2048>, GASM_WG, 0);
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_bucket_dedup<u64, 4096>, GASM_WG, 0);
@@ -372,7 +393,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
             HIPCHK(hipMemcpyAsync(hv.data(), d_stamps, hv.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
             const unsigned long long* h = hv.data();
-            if (FILE* f = fopen(getenv("GASM_DBG_STAMPS"), "wb")) { fwrite(hv.data(), 8, hv.size(), f); fclose(f); }
+            if (FILE* f = fopen(knobs().stamps, "wb")) { fwrite(hv.data(), 8, hv.size(), f); fclose(f); }
             fprintf(stderr, "[dedup stamps, 100 MHz ticks per workgroup] init %.1f  first-iter %.1f  stream %.1f  barrier %.1f  order %.1f  writeback %.1f\n",
                     (double)h[0] / nbt, (double)h[1] / nbt, (double)h[2] / nbt, (double)h[3] / nbt, (double)h[4] / nbt, (double)h[5] / nbt);
         }
@@ -443,7 +464,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     rounds += 1;
     u32* const act = bs.d_flags.as<u32>() + 16;     // "still active" words of the k_link_jump launches, zeroed at the start of the build
     const u32 jchunks = (u32)ceil_div_u64(maxD, GASM_WG * 4);      // GASM_JUMP_ILP links per thread
-    if (maxD <= 65534 && !getenv("GASM_RANK_GLOBAL")) {
+    if (maxD <= 65534 && !knobs().rank_global) {
         // every second edge (the rulers) is ranked inside LDS, the others then need a step or two (kernels_build.hip)
         const u32 max_rulers = (maxD + 1) / 2, rchunks = (u32)ceil_div_u64(max_rulers, GASM_WG);
         GCHK(bs.d_rtab.ensure(((size_t)D / 2 + S + 2) * 4));
@@ -453,7 +474,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
             rank_attr_set = true;
         }
         GLAUNCH(ctx, "k_rank_rulers", k_rank_rulers, seg_grid(rchunks, S), dim3(GASM_WG), 0, gv, S, rchunks, bs.d_link.as<u64>(), bs.d_rtab.as<u32>());
-        GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)max_rulers * 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), getenv("GASM_DBG_RANK_ROUNDS") ? atoi(getenv("GASM_DBG_RANK_ROUNDS")) : 18);
+        GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)max_rulers * 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), knobs().rank_rounds);
         // the odd edges: the ruler behind an edge is usually one or two steps away (a longer gap is geometrically rare)
         // (a thread stops as soon as its link is final; spans grow by a factor of jumps + 1 per launch at the very
         // least, so two launches cover any segment of this size, and the second normally returns at once)
