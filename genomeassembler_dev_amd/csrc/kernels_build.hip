@@ -97,16 +97,18 @@ __device__ __forceinline__ void tile_fetch(const ReadSet& rs, const TileInfo& ti
     r.load(rs.words, nv ? p0 + off0 : 0);
 }
 
-// Bucket counts of every tile: tcnt[tile * nb + b] = k-mers of the tile whose first `bbits` bits are b (16-bit: a tile
-// holds at most GASM_TILE_WG * KT <= 8192).  Buckets are key ranges (bbits <= 2(k-1), bbits <= 10): concatenating
+// Bucket counts of every tile: tcnt[tile * nb + b] = k-mers of the tile whose first `bbits` bits are b, as four 16-bit
+// sub-counts (a tile holds at most GASM_TILE_WG * KT <= 8192): sub-count s is what the threads with (thread & 3) == s
+// contribute.  The same split is used when k_bucket_scatter ranks the k-mers; with it 64 lanes hitting 64 buckets
+// collide on an LDS word a quarter as often (same-address LDS atomics serialise: 12.4 vs 8.4 cycles per instruction).  Buckets are key ranges (bbits <= 2(k-1), bbits <= 10): concatenating
 // sorted buckets gives a sorted segment.
 template <class K>
 __global__ void __launch_bounds__(GASM_TILE_WG) k_tile_hist(ReadSet rs, const uint4* __restrict__ tinfo, int k, int bbits, u32 g, u32 n_tiles,
-                                                            u16* __restrict__ tcnt) {
+                                                            ushort4* __restrict__ tcnt) {
     constexpr u32 KT = KeyTraits<K>::KT;
-    extern __shared__ u32 s_h[];   // [nb]
-    const u32 nb = 1u << bbits;
-    for (u32 e = threadIdx.x; e < nb; e += GASM_TILE_WG) s_h[e] = 0;
+    extern __shared__ u32 s_h[];   // [nb][4]
+    const u32 nb = 1u << bbits, sub = threadIdx.x & 3u;
+    for (u32 e = threadIdx.x; e < 4 * nb; e += GASM_TILE_WG) s_h[e] = 0;
     __syncthreads();
     // the next tile's words are requested before this tile's atomics (one tile of load latency hidden per tile)
     u32 tile = blockIdx.x;
@@ -121,23 +123,28 @@ __global__ void __launch_bounds__(GASM_TILE_WG) k_tile_hist(ReadSet rs, const ui
         if (tnext < n_tiles) tile_fetch<K>(rs, tile_decode(tinfo, tnext), g, k, r, nv);
         static_for<KT>([&](auto J) {
             constexpr u32 j = J;
-            if (j < nv_now) atomicAdd(&s_h[bbits ? w.template top_hi<j>() >> (32 - bbits) : 0u], 1u);
+            if (j < nv_now) atomicAdd(&s_h[(bbits ? w.template top_hi<j>() >> (32 - bbits) : 0u) * 4 + sub], 1u);
         });
         __syncthreads();
-        for (u32 e = threadIdx.x; e < nb; e += GASM_TILE_WG) { tcnt[(u64)tile * nb + e] = (u16)s_h[e]; s_h[e] = 0; }
+        for (u32 e = threadIdx.x; e < nb; e += GASM_TILE_WG) {
+            const uint4 c = *reinterpret_cast<const uint4*>(&s_h[4 * e]);
+            tcnt[(u64)tile * nb + e] = make_ushort4((u16)c.x, (u16)c.y, (u16)c.z, (u16)c.w);
+            *reinterpret_cast<uint4*>(&s_h[4 * e]) = make_uint4(0, 0, 0, 0);
+        }
         __syncthreads();
         if (tnext >= n_tiles) break;
         tile = tnext;
     }
 }
-template __global__ void k_tile_hist<u64>(ReadSet, const uint4*, int, int, u32, u32, u16*);
-template __global__ void k_tile_hist<K128>(ReadSet, const uint4*, int, int, u32, u32, u16*);
+template __global__ void k_tile_hist<u64>(ReadSet, const uint4*, int, int, u32, u32, ushort4*);
+template __global__ void k_tile_hist<K128>(ReadSet, const uint4*, int, int, u32, u32, ushort4*);
 
 // Per segment and bucket: the running sum toff[tile * nb + b] of the tiles' padded counts (offset of the tile's run
 // inside its (segment,bucket) range) and the bucket total hist[seg * nb + b].  One workgroup per segment, thread =
 // bucket.  Each (tile, bucket) run is rounded up to padm + 1 keys — one 128-byte line when the bucket count allows —
 // so that no cache line is written by two workgroups: partial-line writes cost more than half the store bandwidth.
-__global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 padm, const u16* __restrict__ tcnt,
+__device__ __forceinline__ u32 sub_total(ushort4 c) { return (u32)c.x + c.y + c.z + c.w; }
+__global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 padm, const ushort4* __restrict__ tcnt,
                                                     u32* __restrict__ toff, u32* __restrict__ hist) {
     __shared__ u32 s_part[1024];
     const u32 nb = 1u << bbits, seg = blockIdx.x;
@@ -149,7 +156,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 p
     for (u32 b0 = 0; b0 < nb; b0 += nbw) {
         const u32 b = b0 + bl;
         u32 sum = 0;
-        for (u32 t = ta; t < tb; ++t) sum += ((u32)tcnt[(u64)t * nb + b] + padm) & ~padm;
+        for (u32 t = ta; t < tb; ++t) sum += (sub_total(tcnt[(u64)t * nb + b]) + padm) & ~padm;
         s_part[threadIdx.x] = sum;
         __syncthreads();
         u32 run = 0;
@@ -158,7 +165,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 p
         __syncthreads();
         for (u32 t = ta; t < tb; ++t) {
             toff[(u64)t * nb + b] = run;
-            run += ((u32)tcnt[(u64)t * nb + b] + padm) & ~padm;
+            run += (sub_total(tcnt[(u64)t * nb + b]) + padm) & ~padm;
         }
     }
 }
@@ -246,29 +253,29 @@ __global__ void __launch_bounds__(64) k_seg_offsets(const u32* __restrict__ seg_
 // ================================================================================================================
 template <class K> struct TilePrefetch {
     Roll<K> rl;
-    u32 nv, cnt, toff, bs_lo, bs_hi;      // (the sum bstart + toff is formed after the wait, not when they are requested)
+    u32 nv, c01, c23, toff, bs_lo, bs_hi; // sub-counts packed as loaded (the sums are formed after the wait, not at the request)
     // explicit wait: everything requested at least N vector-memory operations ago has arrived
     template <int N> __device__ __forceinline__ void wait_all_but() {
         rl.template wait_all_but<N>();
-        __asm__ volatile("" : "+v"(cnt), "+v"(toff), "+v"(bs_lo), "+v"(bs_hi));     // ordered behind the wait above ("memory")
+        __asm__ volatile("" : "+v"(c01), "+v"(c23), "+v"(toff), "+v"(bs_lo), "+v"(bs_hi));     // ordered behind the wait above ("memory")
     }
 };
 
 template <class K>
 __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_scatter(ReadSet rs, const uint4* __restrict__ tinfo, int k, int bbits, u32 g, u32 padm,
                                                                   u32 n_tiles, const u64* __restrict__ bstart, const u32* __restrict__ toff,
-                                                                  const u16* __restrict__ tcnt, K* __restrict__ keys, u64 scratch) {
+                                                                  const ushort4* __restrict__ tcnt, K* __restrict__ keys, u64 scratch) {
     extern __shared__ __align__(16) unsigned char s_raw[];
     constexpr u32 KT = KeyTraits<K>::KT;
     constexpr u32 NFL = KeyTraits<K>::NFL;               // flush passes of 16 bytes per thread: the tile + room for the padding
     constexpr u32 KPU = 16 / sizeof(K);                  // keys per 16-byte unit
     constexpr u32 CAP = NFL * GASM_TILE_WG * KPU;
     const u32 nb = 1u << bbits;
-    const u32 tid = threadIdx.x, wv = tid >> 6, ln = tid & 63;
+    const u32 tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, sub = tid & 3u;
     K* s_key = reinterpret_cast<K*>(s_raw);                                  // CAP + one trash slot per thread
     u64* s_comb = reinterpret_cast<u64*>(s_key + CAP + GASM_TILE_WG);        // nb
-    u32* s_cur = reinterpret_cast<u32*>(s_comb + nb);                        // nb + 2 (dummy bin)
-    u32* s_tmp = s_cur + nb + 2;                                             // 12
+    u32* s_cur = reinterpret_cast<u32*>(s_comb + ((nb + 1) & ~1u));          // 4 per bucket (sub-cursors) + dummy bin; 16-byte aligned
+    u32* s_tmp = s_cur + 4 * nb + 4;                                         // 12
     const int bshift = 2 * k - bbits;
     const bool one = nb <= GASM_TILE_WG;                                     // one bucket per thread, prefetched
 
@@ -280,9 +287,10 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
     const u64 my_scratch = scratch + (u64)(((blockIdx.x & 1023u) * (GASM_TILE_WG / 64) + wv) * 64 + ln) * KPU;
 
     auto fetch = [&](u32 t, const TileInfo& ti, TilePrefetch<K>& pf) {
-        pf.cnt = 0; pf.toff = 0; pf.bs_lo = 0; pf.bs_hi = 0;
+        pf.c01 = 0; pf.c23 = 0; pf.toff = 0; pf.bs_lo = 0; pf.bs_hi = 0;
         if (one && tid < nb) {
-            pf.cnt = tcnt[(u64)t * nb + tid];
+            const uint2 c = reinterpret_cast<const uint2*>(tcnt)[(u64)t * nb + tid];
+            pf.c01 = c.x; pf.c23 = c.y;
             pf.toff = toff[(u64)t * nb + tid];
             const uint2 b = reinterpret_cast<const uint2*>(bstart)[(u64)ti.seg * nb + tid];
             pf.bs_lo = b.x; pf.bs_hi = b.y;
@@ -297,10 +305,11 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
         // ---- staging ranges of the buckets
         u32 total;
         if (one) {
-            const u32 cnt = pf.cnt, padc = (cnt + padm) & ~padm;
+            const u32 c0 = pf.c01 & 0xFFFFu, c1 = pf.c01 >> 16, c2 = pf.c23 & 0xFFFFu, c3 = pf.c23 >> 16;
+            const u32 cnt = c0 + c1 + c2 + c3, padc = (cnt + padm) & ~padm;
             const u32 soff = block_excl_scan<GASM_TILE_WG>(padc, s_tmp, &total);
             if (tid < nb) {
-                s_cur[tid] = soff;
+                *reinterpret_cast<uint4*>(&s_cur[4 * tid]) = make_uint4(soff, soff + c0, soff + c0 + c1, soff + c0 + c1 + c2);
                 s_comb[tid] = (((u64)pf.bs_hi << 32) | pf.bs_lo) + pf.toff - soff;   // staging index i goes to keys[s_comb[bucket] + i]
                 for (u32 i = cnt; i < padc; ++i) s_key[soff + i] = key_filler<K>(tid, bshift);
             }
@@ -308,10 +317,11 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
             u32 carry = 0;
             for (u32 b0 = 0; b0 < nb; b0 += GASM_TILE_WG) {
                 const u32 b = b0 + tid;
-                const u32 cnt = tcnt[(u64)tile * nb + b], padc = (cnt + padm) & ~padm;
+                const ushort4 c = tcnt[(u64)tile * nb + b];
+                const u32 cnt = sub_total(c), padc = (cnt + padm) & ~padm;
                 u32 tot;
                 const u32 soff = carry + block_excl_scan<GASM_TILE_WG>(padc, s_tmp, &tot);
-                s_cur[b] = soff;
+                *reinterpret_cast<uint4*>(&s_cur[4 * b]) = make_uint4(soff, soff + c.x, soff + c.x + c.y, soff + c.x + c.y + c.z);
                 s_comb[b] = bstart[(u64)ti.seg * nb + b] + toff[(u64)tile * nb + b] - soff;
                 for (u32 i = cnt; i < padc; ++i) s_key[soff + i] = key_filler<K>(b, bshift);
                 carry += tot;
@@ -329,7 +339,7 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
             constexpr u32 j = J;
             key[j] = w.template key<j>(k);
             const u32 bkt = bbits ? w.template top_hi<j>() >> (32 - bbits) : 0u;
-            idx[j] = atomicAdd(&s_cur[j < nv ? bkt : nb], 1u);
+            idx[j] = atomicAdd(&s_cur[j < nv ? 4 * bkt + sub : 4 * nb], 1u);
         });
         // ---- the next tile's inputs, requested ahead of this tile's stores (the last tile re-requests its own)
         const u32 tnext = tile + 1 < tile_end ? tile + 1 : tile;
@@ -369,8 +379,8 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
         pf.template wait_all_but<NFL>();
     }
 }
-template __global__ void k_bucket_scatter<u64>(ReadSet, const uint4*, int, int, u32, u32, u32, const u64*, const u32*, const u16*, u64*, u64);
-template __global__ void k_bucket_scatter<K128>(ReadSet, const uint4*, int, int, u32, u32, u32, const u64*, const u32*, const u16*, K128*, u64);
+template __global__ void k_bucket_scatter<u64>(ReadSet, const uint4*, int, int, u32, u32, u32, const u64*, const u32*, const ushort4*, u64*, u64);
+template __global__ void k_bucket_scatter<K128>(ReadSet, const uint4*, int, int, u32, u32, u32, const u64*, const u32*, const ushort4*, K128*, u64);
 
 // ================================================================================================================
 // De-duplicate one bucket: stream its keys through an LDS table (count per distinct key), then order the distinct keys

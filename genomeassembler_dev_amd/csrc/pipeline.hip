@@ -337,31 +337,31 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         const u64 n_alloc = N + (u64)padm * rd.n_tiles * nb;
         GCHK(bs.d_keys.ensure((n_alloc + SCRATCH_KEYS) * KB));
         GCHK(bs.d_mult.ensure(n_alloc * 4));
-        GCHK(bs.d_cube.ensure((size_t)rd.n_tiles * nb * 2 + 64));
+        GCHK(bs.d_cube.ensure((size_t)rd.n_tiles * nb * 8 + 64));      // four 16-bit sub-counts per (tile, bucket)
         GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
         GCHK(bs.d_dstart.ensure(((size_t)nbt + 2) * 4));
         HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 256, ctx->stream));
         if (W == 1) {
-            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 4, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
-                    bs.d_cube.as<u16>());
+            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
+                    bs.d_cube.as<ushort4>());
         } else {
-            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 4, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
-                    bs.d_cube.as<u16>());
+            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
+                    bs.d_cube.as<ushort4>());
         }
-        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(1024), 0, rs, bbits, padm, bs.d_cube.as<u16>(),
+        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(1024), 0, rs, bbits, padm, bs.d_cube.as<ushort4>(),
                 bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr, (u32*)nullptr, 0u, 0u);
-        const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 12 + 64;   // KeyTraits<K>::NFL passes + trash slots
+        const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
         // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
         const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
         if (W == 1) {
             GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<u64>(), n_alloc);
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<ushort4>(), bs.d_keys.as<u64>(), n_alloc);
         } else {
             GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<u16>(), bs.d_keys.as<K128>(), n_alloc);
+                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<ushort4>(), bs.d_keys.as<K128>(), n_alloc);
         }
         unsigned long long* d_stamps = nullptr;
         static DBuf stamp_buf;
