@@ -980,17 +980,21 @@ __global__ void __launch_bounds__(1024) k_contig_scan(GraphView gv, const u8* __
     const u32 wa = min(hi, lo + wv * per), wb = min(hi, wa + per);
     u32 ccarry = 0;
     u64 bcarry = 0;
-    for (u32 base = wa; base < wb; base += 256) {
-        u8 ef[4];
-        u32 cl[4];
+    for (u32 base = wa; base < wb; base += 1024) {
+        u32 ef[16];                                                // (32-bit: a byte array would be packed, one dependent load at a time)
+        u32 cl[16];
 #pragma unroll
-        for (u32 q = 0; q < 4; ++q) {                            // eight loads in flight, then the scans
+        for (u32 q = 0; q < 16; ++q) {                           // 32 loads in flight, then the scans: the kernel is load latency
             const u32 i = base + q * 64 + ln;
-            ef[q] = i < wb ? eflag[i] : (u8)0;
+            ef[q] = i < wb ? (u32)eflag[i] : 0u;
             cl[q] = i < wb ? clen[i] : 0u;
         }
+        // (without this the compiler sinks each clen load under "is a head", i.e. behind its flag load: one dependent
+        // round trip per row instead of 32 loads in flight)
 #pragma unroll
-        for (u32 q = 0; q < 4; ++q) {
+        for (u32 q = 0; q < 16; ++q) __asm__ volatile("" : "+v"(cl[q]), "+v"(ef[q]));
+#pragma unroll
+        for (u32 q = 0; q < 16; ++q) {
             const u32 i = base + q * 64 + ln;
             const bool head = ef[q] & 1;
             const u32 len = head ? (u32)(gv.k - 1) + cl[q] : 0u;
@@ -1010,9 +1014,16 @@ __global__ void __launch_bounds__(1024) k_contig_scan(GraphView gv, const u8* __
         if (w < wv) { cbefore += s_cnt[w]; bbefore += s_bas[w]; }
         ctot += s_cnt[w]; btot += s_bas[w];
     }
-    if (wv)     // heads were only just written by this same thread: plain read-modify-write
-        for (u32 i = wa + ln; i < wb; i += 64)
-            if (eflag[i] & 1) { e_cid[i] += cbefore; e_coff[i] += bbefore; }
+    if (wv) {   // heads were only just written by this same thread: plain read-modify-write; 32 flag loads in flight
+        for (u32 base = wa + ln; base < wb; base += 2048) {
+            u32 ef[32];
+#pragma unroll
+            for (u32 q = 0; q < 32; ++q) ef[q] = base + 64 * q < wb ? (u32)eflag[base + 64 * q] : 0u;
+#pragma unroll
+            for (u32 q = 0; q < 32; ++q)
+                if (ef[q] & 1) { e_cid[base + 64 * q] += cbefore; e_coff[base + 64 * q] += bbefore; }
+        }
+    }
     if (threadIdx.x == 0) { seg_ncontig[seg] = ctot; seg_cbases[seg] = btot; }
 }
 
