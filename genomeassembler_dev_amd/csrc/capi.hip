@@ -200,8 +200,13 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
                 s->startpos[p] = (int32_t)(int)truth.find(pth);
             }
         }
-        if (flags & GASM_WANT_LEV) {
-            // lib/DeNovoAssembler.cpp:463 (global) / lib/BreakageScorer.cpp:339 (infix); threads over paths
+        bool lev_done = false;
+        if ((flags & GASM_WANT_LEV) && !getenv("GASM_LEV_HOST")) {
+            // lib/DeNovoAssembler.cpp:463 (global) / lib/BreakageScorer.cpp:339 (infix): one wave per path on the GPU
+            st = pipeline_levenshtein(ctx, dp, true_solution, true_len, velvet, s->lev, &lev_done);
+        }
+        if (st == GASM_OK && (flags & GASM_WANT_LEV) && !lev_done) {
+            // target with bytes outside ACGT (or GASM_LEV_HOST set): the host routine, threads over paths
             std::atomic<u64> next(0);
             unsigned nt = std::thread::hardware_concurrency();
             nt = std::max(1u, std::min(nt, 32u));
@@ -222,7 +227,7 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
         }
     }
     rd.release(); dp.release(); tb.release(); ss.release();
-    if (st != GASM_OK) return st;
+    if (st != GASM_OK) { delete s; return st; }
     *out = s;
     return GASM_OK;
     API_GUARD_END

@@ -110,6 +110,7 @@ __global__ void k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* se
 template <class K>
 __global__ void k_score_reads_graph(ReadSet rs, GraphView gv, const u64* link, const u32* e_cid, PathSet ps, const long long* dfix,
                                     int kmer, u32 reads_per_wg, u32 chunks, u32 lds_paths, u32* cnt, unsigned long long* sum);
+__global__ void k_levenshtein(PathSet ps, u32 n_paths, const u64* twords, u32 nt, int infix, u8* carry_ws, u64 carry_stride, int32_t* out);
 __global__ void k_score_finish(PathSet ps, const u32* cnt, const unsigned long long* sum, const long long* dfix, const u64* seg_empty,
                                int kmer, double inv_scale, double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,
                                int32_t* seq_len, u32 n_paths);

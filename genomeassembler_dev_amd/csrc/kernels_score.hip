@@ -321,3 +321,111 @@ __global__ void __launch_bounds__(GASM_WG) k_prob_dist(PathSet ps, const double*
         out[pd_off[p] + j] = v;
     }
 }
+
+// ================================================================================================================
+// Levenshtein distance of every path against one target (lib/DeNovoAssembler.cpp:41-55 global,
+// lib/BreakageScorer.cpp:41-55 infix; the reference calls edlib, path = query, true solution = target).
+//
+// Myers' bit-vector algorithm in 64-row blocks (the same recurrence as gasm_host::levenshtein), ONE WAVE PER PATH:
+// lane b owns block b of a band of 64 blocks (4096 path bases) and walks the target columns one step behind lane b-1,
+// so the horizontal delta leaving block b-1 at a column reaches lane b through a DPP wave shift in the next step, and
+// so does the target base — no LDS, no barriers.  Paths longer than 4096 bases take several bands; the deltas leaving a
+// band's last block are parked in a per-wave global array (one byte per column, written and read 64 columns at a time
+// through v_readlane and a lane select) and enter the next band's lane 0.  Only the lane with the path's last block keeps
+// the score.  Work is O(|path| * |target| / 64) integer instructions; the waves of a launch are independent.
+// ================================================================================================================
+__device__ __forceinline__ u32 compress_even32(u64 x) {          // bits 0, 2, 4, ... 62 of x, packed
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (u32)x;
+}
+// 32 bases (first base most significant) -> the plane of their high code bits and of their low code bits, base i at bit i
+__device__ __forceinline__ void code_planes32(u64 w, u32* hi, u32* lo) {
+    *lo = __brev(compress_even32(w));
+    *hi = __brev(compress_even32(w >> 1));
+}
+__device__ __forceinline__ int wave_shr1(int v, int lane0) {      // lane b gets lane b-1's v, lane 0 gets lane0
+    return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false);
+}
+
+__global__ void __launch_bounds__(GASM_WG) k_levenshtein(PathSet ps, u32 n_paths, const u64* __restrict__ twords, u32 nt, int infix,
+                                                         u8* __restrict__ carry_ws, u64 carry_stride, int32_t* __restrict__ out) {
+    const u32 ln = threadIdx.x & 63;
+    const u32 wave = (blockIdx.x * GASM_WG + threadIdx.x) >> 6, n_waves = gridDim.x * (GASM_WG / 64);
+    u8* const carry = carry_ws + (u64)wave * carry_stride;         // nt + 64 bytes of this wave
+    for (u32 p = wave; p < n_paths; p += n_waves) {
+        const u64 pb = ps.p_off[p];
+        const u32 nq = (u32)(ps.p_off[p + 1] - pb);
+        if (nq == 0 || nt == 0) { if (ln == 0) out[p] = 0; continue; }     // edlib reports an error, the reference returns 0
+        const u32 nblk = (nq + 63) / 64, nbands = (nblk + 63) / 64;
+        const u32 last_lane = (nblk - 1) & 63;
+        long long score = nq, best = nq;
+        for (u32 band = 0; band < nbands; ++band) {
+            // ---- this lane's block: match masks as two code planes, valid rows, top row
+            const u32 blk = band * 64 + ln;
+            u64 H = 0, L = 0, valid = 0;
+            if (blk < nblk) {
+                const u32 rows = min(64u, nq - blk * 64);
+                u32 h0, l0, h1 = 0, l1 = 0;
+                code_planes32(window32(ps.words, pb + (u64)blk * 64), &h0, &l0);
+                if (rows > 32) code_planes32(window32(ps.words, pb + (u64)blk * 64 + 32), &h1, &l1);
+                H = (u64)h0 | ((u64)h1 << 32);
+                L = (u64)l0 | ((u64)l1 << 32);
+                valid = rows == 64 ? ~0ull : ((1ull << rows) - 1);
+            }
+            const u64 top = blk + 1 == nblk ? (1ull << ((nq - 1) & 63)) : (1ull << 63);
+            const bool last_band = band + 1 == nbands;
+            u64 Pv = ~0ull, Mv = 0;
+            int hout = 0, ch = 0;
+            u32 tch = 0, cin = 0, cout = 0;                       // 64-column chunks: target codes, deltas in, deltas out
+            const int hin0 = infix ? 0 : 1;                       // delta entering block 0 (lib/BreakageScorer.cpp: HW mode)
+            for (u32 s = 0; s < nt + 63; ++s) {
+                if ((s & 63) == 0) {                              // next 64 columns for lane 0
+                    const u32 j = s + ln;
+                    tch = j < nt ? (u32)(twords[j >> 5] >> (62 - 2 * (j & 31))) & 3u : 0u;
+                    if (band) cin = j < nt ? (u32)carry[j] : 1u;
+                }
+                const int ch_new = (int)__builtin_amdgcn_readlane((int)tch, s & 63);
+                const int hin_new = band ? (int)__builtin_amdgcn_readlane((int)cin, s & 63) - 1 : hin0;
+                ch = wave_shr1(ch, ch_new);
+                const int hin = wave_shr1(hout, hin_new);
+                const bool act = s >= ln && s - ln < nt && blk < nblk;
+                // ---- one column of the block (Hyyro's formulation, as gasm_host::levenshtein)
+                const u64 hm = (ch & 2) ? ~0ull : 0ull, lm = (ch & 1) ? ~0ull : 0ull;
+                u64 eq = ~((H ^ hm) | (L ^ lm)) & valid;
+                const u64 xv = eq | Mv;
+                if (hin < 0) eq |= 1;
+                const u64 xh = (((eq & Pv) + Pv) ^ Pv) | eq;
+                u64 ph = Mv | ~(xh | Pv);
+                u64 mh = Pv & xh;
+                const int ho = (ph & top) ? 1 : ((mh & top) ? -1 : 0);
+                ph <<= 1;
+                mh <<= 1;
+                if (hin < 0) mh |= 1;
+                else if (hin > 0) ph |= 1;
+                if (act) {
+                    Pv = mh | ~(xv | ph);
+                    Mv = ph & xv;
+                    hout = ho;
+                    if (last_band && ln == last_lane) { score += ho; best = score < best ? score : best; }
+                }
+                // ---- the delta leaving the band's last block, column s - 63, parked for the next band
+                if (!last_band && s >= 63) {
+                    const u32 j = s - 63;
+                    const int h63 = __builtin_amdgcn_readlane(hout, 63);
+                    if (ln == (j & 63)) cout = (u32)(h63 + 1);
+                    if ((j & 63) == 63 || j + 1 == nt) {
+                        const u32 jj = (j & ~63u) + ln;
+                        if (jj < nt) carry[jj] = (u8)cout;
+                    }
+                }
+            }
+        }
+        const long long sc = __shfl(infix ? best : score, (int)last_lane, 64);
+        if (ln == 0) out[p] = (int32_t)sc;
+    }
+}

@@ -100,3 +100,6 @@ int pipeline_contig_paths(gasm_ctx* ctx, const DevReads& rd, const BuildState& b
 int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, const ScoreTable& tb, bool want_freq,
                           bool want_pd, ScoreState& ss, const BuildState* graph);
 int pipeline_score_fetch(gasm_ctx* ctx, ScoreState& ss);
+// Levenshtein distance of every path of `dp` against `target` (ASCII) on the GPU (k_levenshtein).  *done = false when
+// the target holds a byte outside ACGT (the packed form cannot represent it): the caller then uses the host routine.
+int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 target_len, bool infix, std::vector<int32_t>& lev, bool* done);

@@ -658,6 +658,43 @@ int ScoreTable::set_fixed(gasm_ctx* ctx, u64 max_terms) {
     return GASM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Levenshtein distances
+// ---------------------------------------------------------------------------------------------------------------
+int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 target_len, bool infix, std::vector<int32_t>& lev, bool* done) {
+    *done = false;
+    const u32 P = dp.n_paths;
+    lev.assign(P, 0);
+    if (P == 0 || target_len == 0) { *done = true; return GASM_OK; }      // (empty target: the reference returns 0)
+    if (target_len >= 0xFFFFFF00ull) return GASM_OK;                       // host routine
+    HIPCHK(hipSetDevice(ctx->device));
+    DBuf ascii, err, twords, carry, d_out;
+    GCHK(err.ensure(8));
+    HIPCHK(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+    GCHK(h2d(ctx, ascii, target, target_len));
+    int st = pack_ascii(ctx, ascii.as<u8>(), target_len, twords, err.as<u32>());
+    u32 herr = 0;
+    if (st == GASM_OK && hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
+    if (st == GASM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
+    if (st != GASM_OK || herr) { ascii.release(); err.release(); twords.release(); return st; }   // not ACGT: host routine
+    // one wave per path, at most 16 waves per CU resident-ish; every wave parks one byte per target column
+    const u32 waves = std::min<u32>(P, (u32)ctx->n_cu * 16u);
+    const u32 wgs = (waves + GASM_WG / 64 - 1) / (GASM_WG / 64);
+    const u64 stride = (target_len + 64 + 63) & ~(u64)63;
+    st = carry.ensure((size_t)wgs * (GASM_WG / 64) * stride);
+    if (st == GASM_OK) st = d_out.ensure((size_t)P * 4);
+    if (st == GASM_OK) {
+        hipLaunchKernelGGL(k_levenshtein, dim3(wgs), dim3(GASM_WG), 0, ctx->stream, dp.view(), P, twords.as<u64>(), (u32)target_len, infix ? 1 : 0,
+                           carry.as<u8>(), stride, d_out.as<int32_t>());
+        if (hipGetLastError() != hipSuccess) st = GASM_ERR_HIP;
+    }
+    if (st == GASM_OK && hipMemcpyAsync(lev.data(), d_out.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
+    if (st == GASM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { gasm_set_error("k_levenshtein failed"); st = GASM_ERR_HIP; }
+    ascii.release(); err.release(); twords.release(); carry.release(); d_out.release();
+    if (st == GASM_OK) *done = true;
+    return st;
+}
+
 void ScoreTable::release() { d_prob.release(); d_row.release(); d_fix.release(); }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -227,6 +227,40 @@ def test_large_segment_long_reads_and_cycles(qtable):
         b.close()
 
 
+def test_levenshtein_kernel_against_oracle(qtable):
+    """k_levenshtein (one wave per path, Myers blocks passed lane to lane): global distance for the own-assembler variant,
+    infix for the velvet one; path lengths around the 64-row block and the 4096-row band boundaries, mutated copies of
+    pieces of the truth, a path that is the truth, one longer than the truth, and an empty path."""
+    keys, prob = qtable
+    rng = np.random.default_rng(11)
+    truth = _strs(synth.make_segment(201, 6001, planted=False)[None, :])[0]
+
+    def mutate(s, n):
+        s = list(s)
+        for _ in range(n):
+            i = int(rng.integers(0, max(1, len(s))))
+            r = int(rng.integers(0, 3))
+            if r == 0 and s:
+                s[i] = "ACGT"[int(rng.integers(0, 4))]
+            elif r == 1:
+                s.insert(i, "ACGT"[int(rng.integers(0, 4))])
+            elif s:
+                del s[i]
+        return "".join(s)
+
+    paths = [truth, mutate(truth, 40), truth[100:101], truth[:63], truth[5:69], mutate(truth[900:965], 3), truth[1000:5095],
+             mutate(truth[1000:5096], 25), mutate(truth[200:4297], 60), mutate(truth, 300) + truth[:700], "", "ACGT" * 30]
+    reads = [truth[i:i + 40] for i in range(0, 5900, 50)]
+    for variant in ("own", "velvet"):
+        m = ga.calc_breakscore(paths, reads, truth, 8, keys, prob, variant=variant, with_lev=True, with_freq=False)
+        ref = [orc.levenshtein(p, truth, infix=(variant == "velvet")) for p in paths]
+        assert m["lev_dist_vs_true"].tolist() == ref, variant
+    # a target with a byte outside ACGT goes through the host routine
+    t2 = truth[:500] + "N" + truth[500:900]
+    m = ga.calc_breakscore(paths[2:6], reads, t2, 8, keys, prob, variant="own", with_lev=True, with_freq=False)
+    assert m["lev_dist_vs_true"].tolist() == [orc.levenshtein(p, t2) for p in paths[2:6]]
+
+
 # ------------------------------------------------------------------------------------------------ calc_breakscore
 def _score_case(seed, L=1200, rl=20, cov=40, k=15):
     g = synth.make_segment(seed, L, n_short=3, short_len=60, n_long=1, long_len=150, tandem_len=60, planted=True)
