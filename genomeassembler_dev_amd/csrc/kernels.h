@@ -102,11 +102,12 @@ __global__ void k_contig_emit(GraphView gv, const u8* eflag, const u64* link, co
 // ---- kernels_score.hip
 struct SeedTable {
     u64* seed;            // slot -> seed value
-    u32* gpos;            // slot -> global base position of the window (GASM_NONE32 = empty)
+    u32* gpos;            // slot -> read index (GASM_NONE32 = empty)
     const u64* tbl_off;   // n_segments+1 slot offsets; every segment's table size is a power of two
 };
-__global__ void k_seed_insert(PathSet ps, SeedTable st, const u64* seg_base_off, int w);
-__global__ void k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, u32* poscnt);
+__global__ void k_read_insert(ReadSet rs, SeedTable st, int w);
+__global__ void k_path_scan(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, const u64* first_off, u32* first);
+__global__ void k_first_to_poscnt(const u32* first, u64 n, u32* poscnt);
 template <class K>
 __global__ void k_score_reads_graph(ReadSet rs, GraphView gv, const u64* link, const u32* e_cid, PathSet ps, const long long* dfix,
                                     int kmer, u32 reads_per_wg, u32 chunks, u32 lds_paths, u32* cnt, unsigned long long* sum);

@@ -37,24 +37,15 @@ __device__ __forceinline__ bool break_window(const u64* __restrict__ words, u64 
     return true;
 }
 
-__global__ void __launch_bounds__(GASM_WG) k_seed_insert(PathSet ps, SeedTable st, const u64* __restrict__ seg_base_off, int w) {
-    const u32 seg = blockIdx.y;
-    const u64 lo = seg_base_off[seg], hi = seg_base_off[seg + 1];
-    const u64 g = lo + (u64)blockIdx.x * GASM_WG + threadIdx.x;
-    if (g + (u64)w > hi) return;
-    const u64 seed = kmer_at(ps.words, g, w);
-    const u64 tb = st.tbl_off[seg];
-    const u32 mask = (u32)(st.tbl_off[seg + 1] - tb) - 1;
-    u32 h = hash64(seed) & mask;
-    while (true) {
-        const u32 old = atomicCAS(&st.gpos[tb + h], GASM_NONE32, (u32)g);
-        if (old == GASM_NONE32) { st.seed[tb + h] = seed; break; }
-        h = (h + 1) & mask;
-    }
-}
-
-__global__ void __launch_bounds__(GASM_WG) k_read_match(ReadSet rs, PathSet ps, SeedTable st, const u64* __restrict__ seg_base_off,
-                                                        int w, u32* __restrict__ poscnt) {
+// ---- API path (arbitrary paths, e.g. the scaffolds of assemble_contigs): index the READS, scan the PATHS ----------
+// lib/DeNovoAssembler.cpp:346-392 tests every read against every path and takes the first occurrence.  Scaffolds repeat
+// the same genome over and over (thousands of paths, each most of the segment), so an index over path positions has
+// chains as long as the number of paths; the reads of a segment, on the other hand, are few and mostly start at
+// different places.  So: a small open-addressing table of the reads keyed by their first w bases (k_read_insert); one
+// thread per path position looks its window up, verifies every read that starts like it, and keeps the smallest
+// position per (path, read) with an atomicMin in a dense table (k_path_scan); the first occurrences then become the
+// position counters the reductions work from (k_first_to_poscnt).
+__global__ void __launch_bounds__(GASM_WG) k_read_insert(ReadSet rs, SeedTable st, int w) {
     const u32 seg = blockIdx.y;
     const u64 r = rs.seg_read_off[seg] + (u64)blockIdx.x * GASM_WG + threadIdx.x;
     if (r >= rs.seg_read_off[seg + 1]) return;
@@ -65,37 +56,76 @@ __global__ void __launch_bounds__(GASM_WG) k_read_match(ReadSet rs, PathSet ps, 
     const u64 seed = kmer_at(rs.words, p0, w);
     const u64 tb = st.tbl_off[seg];
     const u32 mask = (u32)(st.tbl_off[seg + 1] - tb) - 1;
-    const u32 h0 = hash64(seed) & mask;
-    const u32 pfirst = ps.seg_path_off[seg], plast = ps.seg_path_off[seg + 1];
-    if (pfirst == plast) return;
-    (void)seg_base_off;
-    long long last_g = -1;
-    u32 last_path = GASM_NONE32;
+    u32 h = hash64(seed) & mask;
     while (true) {
-        // smallest candidate position beyond the last one handled, among the slots of this probe sequence
-        u32 best = GASM_NONE32;
-        u32 h = h0;
-        while (true) {
-            const u32 gp = st.gpos[tb + h];
-            if (gp == GASM_NONE32) break;
-            if ((long long)gp > last_g && gp < best && st.seed[tb + h] == seed) best = gp;
-            h = (h + 1) & mask;
-        }
-        if (best == GASM_NONE32) break;
-        last_g = best;
-        const u32 c = pfirst + upper_seg<u64>(ps.p_off + pfirst, plast - pfirst, (u64)best);
-        if (c == last_path) continue;  // an earlier position of this path already matched (first occurrence wins)
-        if ((u64)best + len > ps.p_off[c + 1]) continue;
-        bool same = true;
-        for (u32 o = 0; o < len && same; o += 32) {
-            const u32 nbase = len - o < 32 ? len - o : 32;
-            const u64 a = window32(rs.words, p0 + o), b = window32(ps.words, (u64)best + o);
-            same = ((a ^ b) >> (64 - 2 * nbase)) == 0;
-        }
-        if (!same) continue;
-        last_path = c;
-        atomicAdd(&poscnt[best], 1u);   // kmer_breaks of the path = sum of its position counters (k_path_reduce)
+        const u32 old = atomicCAS(&st.gpos[tb + h], GASM_NONE32, (u32)r);
+        if (old == GASM_NONE32) { st.seed[tb + h] = seed; break; }
+        h = (h + 1) & mask;
     }
+}
+
+// `len` bases of two packed streams equal?  128 bases per round: five words from either stream (independent loads; both
+// streams end in four padding words), aligned in registers.
+__device__ __forceinline__ bool bases_equal(const u64* __restrict__ aw, u64 a0, const u64* __restrict__ bw, u64 b0, u32 len) {
+    bool same = true;
+    for (u32 o = 0; o < len && same; o += 128) {
+        const u64 ra = (a0 + o) >> 5, ca = (b0 + o) >> 5;
+        const u32 sr = (u32)((a0 + o) & 31) << 1, sc = (u32)((b0 + o) & 31) << 1;
+        u64 rw[5], cw[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { rw[i] = aw[ra + i]; cw[i] = bw[ca + i]; }
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            if (o + 32 * j >= len) break;
+            const u32 left = len - o - 32 * j, nbase = left < 32 ? left : 32;
+            const u64 x = funnel64(rw[j], rw[j + 1], sr), y = funnel64(cw[j], cw[j + 1], sc);
+            same = same && ((x ^ y) >> (64 - 2 * nbase)) == 0;
+        }
+    }
+    return same;
+}
+
+// first[first_off[seg] + (path - first path of seg) * reads of seg + (read - first read of seg)] = smallest global base
+// position at which the read occurs in the path (GASM_NONE32: nowhere)
+__global__ void __launch_bounds__(GASM_WG) k_path_scan(ReadSet rs, PathSet ps, SeedTable st, const u64* __restrict__ seg_base_off, int w,
+                                                       const u64* __restrict__ first_off, u32* __restrict__ first) {
+    __shared__ u32 s_c0;
+    const u32 seg = blockIdx.y;
+    const u64 lo = seg_base_off[seg], hi = seg_base_off[seg + 1];
+    const u64 g0 = lo + (u64)blockIdx.x * GASM_WG;
+    if (g0 >= hi) return;
+    const u32 pfirst = ps.seg_path_off[seg], plast = ps.seg_path_off[seg + 1];
+    if (threadIdx.x == 0) s_c0 = pfirst + upper_seg<u64>(ps.p_off + pfirst, plast - pfirst, g0);   // path of the block's first base
+    __syncthreads();
+    const u64 g = g0 + threadIdx.x;
+    if (g >= hi) return;
+    u32 c = s_c0;
+    while (g >= ps.p_off[c + 1]) ++c;             // a block spans a path boundary now and then (empty paths: several)
+    const u64 pend = ps.p_off[c + 1];
+    if (g + (u64)w > pend) return;
+    const u64 seed = kmer_at(ps.words, g, w);
+    const u64 tb = st.tbl_off[seg];
+    const u32 mask = (u32)(st.tbl_off[seg + 1] - tb) - 1;
+    const u64 rfirst = rs.seg_read_off[seg], nreads = rs.seg_read_off[seg + 1] - rfirst;
+    u32* const row = first + first_off[seg] + (u64)(c - pfirst) * nreads;
+    for (u32 h = hash64(seed) & mask;; h = (h + 1) & mask) {
+        const u32 r = st.gpos[tb + h];
+        if (r == GASM_NONE32) break;
+        if (st.seed[tb + h] != seed) continue;
+        u64 p0; u32 len;
+        if (rs.fixed_len) { p0 = (u64)r * rs.fixed_len; len = rs.fixed_len; }
+        else { p0 = rs.read_off[r]; len = (u32)(rs.read_off[r + 1] - p0); }
+        if (g + len > pend) continue;
+        if (!bases_equal(rs.words, p0, ps.words, g, len)) continue;
+        atomicMin(&row[r - rfirst], (u32)g);
+    }
+}
+
+__global__ void __launch_bounds__(GASM_WG) k_first_to_poscnt(const u32* __restrict__ first, u64 n, u32* __restrict__ poscnt) {
+    const u64 i = (u64)blockIdx.x * GASM_WG + threadIdx.x;
+    if (i >= n) return;
+    const u32 g = first[i];
+    if (g != GASM_NONE32) atomicAdd(&poscnt[g], 1u);   // kmer_breaks of the path = sum of its position counters (k_path_reduce)
 }
 
 // Batch path: the paths are the contigs of the same build, so the index already exists.  A read of length >= k starts
@@ -122,23 +152,8 @@ __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& g
     *path = c;
     const u64 g = ps.p_off[c] + ((u32)l & 0x7FFFFFFFu);
     if (g + len > ps.p_off[c + 1]) return ~0ull;
-    // 128 bases per round: five words from either stream (independent loads; both streams end in four padding words),
-    // aligned in registers.  Word-by-word with an early exit was a chain of dependent round trips per read.
-    bool same = true;
-    for (u32 o = 0; o < len && same; o += 128) {
-        const u64 ra = (p0 + o) >> 5, ca = (g + o) >> 5;
-        const u32 sr = (u32)((p0 + o) & 31) << 1, sc = (u32)((g + o) & 31) << 1;
-        u64 rw[5], cw[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) { rw[i] = rs.words[ra + i]; cw[i] = ps.words[ca + i]; }
-#pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-            if (o + 32 * j >= len) break;
-            const u32 left = len - o - 32 * j, nbase = left < 32 ? left : 32;
-            const u64 x = funnel64(rw[j], rw[j + 1], sr), y = funnel64(cw[j], cw[j + 1], sc);
-            same = same && ((x ^ y) >> (64 - 2 * nbase)) == 0;
-        }
-    }
+    // (128 bases per round, aligned in registers: word-by-word with an early exit was a chain of dependent round trips)
+    const bool same = bases_equal(rs.words, p0, ps.words, g, len);
     return same ? g : ~0ull;
 }
 

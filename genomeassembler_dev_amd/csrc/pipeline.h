@@ -80,7 +80,7 @@ struct ScoreTable {
 };
 
 struct ScoreState {
-    DBuf d_tbl_off, d_seed, d_gpos, d_poscnt, d_total, d_out_f64, d_out_i32, d_freq, d_pd_off, d_pd, d_seg_empty, d_fxsum;
+    DBuf d_tbl_off, d_seed, d_gpos, d_poscnt, d_total, d_out_f64, d_out_i32, d_freq, d_pd_off, d_pd, d_seg_empty, d_fxsum, d_first, d_first_off;
     std::vector<u64> h_toff;
     u32 n_paths = 0, n_table = 0;
     bool want_freq = false, want_pd = false, launched = false;

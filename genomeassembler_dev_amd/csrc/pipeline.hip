@@ -239,7 +239,7 @@ void BuildState::release() {
 }
 
 void ScoreState::release() {
-    for (DBuf* b : {&d_tbl_off, &d_seed, &d_gpos, &d_poscnt, &d_total, &d_out_f64, &d_out_i32, &d_freq, &d_pd_off, &d_pd, &d_seg_empty, &d_fxsum}) b->release();
+    for (DBuf* b : {&d_tbl_off, &d_seed, &d_gpos, &d_poscnt, &d_total, &d_out_f64, &d_out_i32, &d_freq, &d_pd_off, &d_pd, &d_seg_empty, &d_fxsum, &d_first, &d_first_off}) b->release();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -758,31 +758,44 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
                     d_fx);
         }
     } else if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
-        // per-segment seed tables: power-of-two, at least twice the number of path positions
+        // per-segment read tables (power of two, at least twice the reads) and the dense first-occurrence table
         std::vector<u64>& toff = ss.h_toff;
         toff.assign((size_t)S + 1, 0);
+        std::vector<u64> foff((size_t)S + 1, 0);
         u64 max_bases = 0, max_reads = 0;
         for (u32 s = 0; s < S; ++s) {
             const u64 nbases = dp.h_seg_base_off[s + 1] - dp.h_seg_base_off[s];
+            const u64 nreads = rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s];
+            const u64 npaths = dp.h_seg_path_off[s + 1] - dp.h_seg_path_off[s];
             u64 slots = 2;
-            while (slots < 2 * nbases) slots <<= 1;
+            while (slots < 2 * nreads) slots <<= 1;
             toff[s + 1] = toff[s] + slots;
+            foff[s + 1] = foff[s] + npaths * nreads;
             max_bases = std::max(max_bases, nbases);
-            max_reads = std::max(max_reads, rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]);
+            max_reads = std::max(max_reads, nreads);
         }
+        if (foff[S] > (8ull << 30)) {
+            gasm_set_error("paths x reads = %llu first-occurrence entries (more than 2^33): score the paths in several calls", (unsigned long long)foff[S]);
+            return GASM_ERR_CAPACITY;
+        }
+        if (rd.n_reads > 0xFFFFFFF0ull || TB > 0xFFFFFFF0ull) { gasm_set_error("too many reads or path bases for 32-bit indices"); return GASM_ERR_CAPACITY; }
         GCHK(h2d(ctx, ss.d_tbl_off, toff.data(), toff.size() * 8));
+        GCHK(h2d(ctx, ss.d_first_off, foff.data(), foff.size() * 8));
         GCHK(ss.d_seed.ensure(toff[S] * 8));
         GCHK(ss.d_gpos.ensure(toff[S] * 4));
+        GCHK(ss.d_first.ensure(foff[S] * 4 + 16));
         HIPCHK(hipMemsetAsync(ss.d_gpos.p, 0xFF, toff[S] * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(ss.d_first.p, 0xFF, foff[S] * 4 + 16, ctx->stream));
         SeedTable st;
         st.seed = ss.d_seed.as<u64>();
         st.gpos = ss.d_gpos.as<u32>();
         st.tbl_off = ss.d_tbl_off.as<u64>();
-        if (max_bases) {
-            GLAUNCH(ctx, "k_seed_insert", k_seed_insert, dim3(ceil_div_u64(max_bases, GASM_WG), S), dim3(GASM_WG), 0, ps, st,
-                    dp.seg_base_off_dev(), w);
-            GLAUNCH(ctx, "k_read_match", k_read_match, dim3(ceil_div_u64(max_reads, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), ps, st,
-                    dp.seg_base_off_dev(), w, ss.d_poscnt.as<u32>());
+        if (max_bases && max_reads) {
+            GLAUNCH(ctx, "k_read_insert", k_read_insert, dim3(ceil_div_u64(max_reads, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), st, w);
+            GLAUNCH(ctx, "k_path_scan", k_path_scan, dim3(ceil_div_u64(max_bases, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), ps, st,
+                    dp.seg_base_off_dev(), w, ss.d_first_off.as<u64>(), ss.d_first.as<u32>());
+            GLAUNCH(ctx, "k_first_to_poscnt", k_first_to_poscnt, dim3(ceil_div_u64(foff[S], GASM_WG)), dim3(GASM_WG), 0, ss.d_first.as<u32>(),
+                    foff[S], ss.d_poscnt.as<u32>());
         }
     }
     if (P && rd.n_empty && !use_graph) {

@@ -227,6 +227,23 @@ def test_large_segment_long_reads_and_cycles(qtable):
         b.close()
 
 
+def test_calc_breakscore_scaffold_like_paths(qtable):
+    """many paths that repeat the same stretches of one genome (what assemble_contigs hands to calc_breakscore), duplicate
+    reads, a read that occurs twice inside a path (first occurrence counts), paths shorter than a read, an empty path"""
+    keys, prob = qtable
+    rng = np.random.default_rng(21)
+    g = _strs(synth.make_segment(301, 1500, planted=False)[None, :])[0]
+    g = g[:700] + g[100:400] + g[700:]                      # a 300-base repeat: reads inside it occur twice in long paths
+    paths = [g[a:a + int(rng.integers(30, 1200))] for a in rng.integers(0, 900, 120)] + [g, g[:20], "", g[50:1700], g]
+    reads = [g[a:a + 36] for a in rng.integers(0, len(g) - 36, 900)]
+    reads += reads[:100] + [g[150:150 + 36]] * 7
+    for variant in ("own", "velvet"):
+        m = ga.calc_breakscore(paths, reads, g, 8, keys, prob, variant=variant, with_lev=False, with_freq=(variant == "own"))
+        o = orc.calc_breakscore(paths, reads, g, 8, keys, prob, velvet=(variant == "velvet"), with_lev=False,
+                                with_freq=(variant == "own"))
+        _check_scores(m, o, with_lev=False)
+
+
 def test_levenshtein_kernel_against_oracle(qtable):
     """k_levenshtein (one wave per path, Myers blocks passed lane to lane): global distance for the own-assembler variant,
     infix for the velvet one; path lengths around the 64-row block and the 4096-row band boundaries, mutated copies of

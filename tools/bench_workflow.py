@@ -1,0 +1,36 @@
+"""The reference's experiment for ONE segment, stage by stage, through the drop-in API (lib/DeNovoAssembler.R:109-346):
+reads -> k-mers -> get_contigs (+ shuffle matrix) -> assemble_contigs -> calc_breakscore of every scaffold (with
+Levenshtein).  usage: python tools/bench_workflow.py [matrix_rows] [segment_len] [coverage]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+cov = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+
+import genomeassembler_dev_amd as ga  # noqa: E402
+from genomeassembler_dev_amd import qtable, synth  # noqa: E402
+
+g = synth.make_segment(1234, L, planted=True)
+reads = [r.tobytes().decode() for r in synth.simulate_reads(g, 150, cov, 1234 + 10000019)]
+truth = g.tobytes().decode()
+keys, prob = qtable.keys(), qtable.load_normalised()
+k = 31
+ga.get_contigs(ga.get_kmers_from_reads(reads[:50], k), k, 1, matrix_rows=2)      # warm up (context, kernels)
+
+
+def timed(name, f):
+    t0 = time.perf_counter()
+    r = f()
+    print(f"{name:34s} {(time.perf_counter() - t0) * 1e3:10.1f} ms")
+    return r
+
+
+km = timed("get_kmers_from_reads (host)", lambda: ga.get_kmers_from_reads(reads, k))
+m = timed(f"get_contigs ({rows} shuffles)", lambda: ga.get_contigs(km, k, 1234, matrix_rows=rows))
+sc = timed("assemble_contigs (host merge)", lambda: ga.assemble_contigs(m, k))
+print(f"  contigs {len(m.contigs)}, scaffolds {len(sc)}, scaffold bases {sum(map(len, sc))}")
+timed("calc_breakscore, no lev", lambda: ga.calc_breakscore(sc, reads, truth, 8, keys, prob, with_lev=False, with_freq=False))
+timed("calc_breakscore, with lev (GPU)", lambda: ga.calc_breakscore(sc, reads, truth, 8, keys, prob, with_lev=True, with_freq=False))
