@@ -78,6 +78,35 @@ def test_shuffle_and_assemble_match_oracle():
         assert ga.assemble_contigs([[contigs[j] for j in row] for row in m], k) == orc.assemble_contigs(contigs, m, k)
 
 
+def test_assemble_index_merge_randomised_against_oracle():
+    """the index form of the merge (suffix/prefix matches precomputed per contig pair, chains of contig ids, strings built
+    once per distinct chain) against the oracle's string form: windows of a genome overlapping by k-1, random extras,
+    contigs only k-1 long, and a chain that spells another contig exactly (the `c[i] != c[j]` test of the reference)."""
+    rng = np.random.default_rng(5)
+
+    def rnd(n):
+        return "".join("ACGT"[i] for i in rng.integers(0, 4, n))
+
+    done = 0
+    for trial in range(40):
+        k = int(rng.integers(3, 12))
+        g = rnd(int(rng.integers(60, 400)))
+        cuts = sorted(set(rng.integers(0, len(g) - k, int(rng.integers(3, 14))).tolist() + [0]))
+        contigs = [g[a:min(len(g), b + k - 1)] for a, b in zip(cuts, cuts[1:] + [len(g)])]
+        contigs += [rnd(int(rng.integers(k - 1, 30))) for _ in range(int(rng.integers(0, 4)))]
+        contigs = sorted(set(c for c in contigs if len(c) >= k - 1))
+        if len(contigs) < 2:
+            continue
+        rows = int(rng.integers(1, 80))
+        assert ga.assemble_contigs_velvet(contigs, k, 7 + trial, rows=rows) == orc.assemble_contigs_velvet(contigs, k, 7 + trial, rows=rows)
+        done += 1
+    assert done > 30
+    # "ACGT" + "GTAC"[2:] == "ACGTAC", which is also a contig: equal strings must not be merged into each other
+    for seed in range(6):
+        contigs = ["ACGT", "ACGTAC", "GTAC", "TTGA"]
+        assert ga.assemble_contigs_velvet(contigs, 3, seed, rows=20) == orc.assemble_contigs_velvet(contigs, 3, seed, rows=20)
+
+
 def test_assemble_short_contig_raises_like_reference():
     with pytest.raises(IndexError):
         ga.assemble_contigs_velvet(["ACG", "TTTTTTTT"], 6, 1, rows=3)
