@@ -396,45 +396,45 @@ __global__ void __launch_bounds__(GASM_WG) k_levenshtein(PathSet ps, u32 n_paths
             const bool last_band = band + 1 == nbands;
             u64 Pv = ~0ull, Mv = 0;
             int hout = 0, ch = 0;
-            u32 tch = 0, cin = 0, cout = 0;                       // 64-column chunks: target codes, deltas in, deltas out
             const int hin0 = infix ? 0 : 1;                       // delta entering block 0 (lib/BreakageScorer.cpp: HW mode)
-            for (u32 s = 0; s < nt + 63; ++s) {
-                if ((s & 63) == 0) {                              // next 64 columns for lane 0
-                    const u32 j = s + ln;
-                    tch = j < nt ? (u32)(twords[j >> 5] >> (62 - 2 * (j & 31))) & 3u : 0u;
-                    if (band) cin = j < nt ? (u32)carry[j] : 1u;
-                }
-                const int ch_new = (int)__builtin_amdgcn_readlane((int)tch, s & 63);
-                const int hin_new = band ? (int)__builtin_amdgcn_readlane((int)cin, s & 63) - 1 : hin0;
-                ch = wave_shr1(ch, ch_new);
-                const int hin = wave_shr1(hout, hin_new);
-                const bool act = s >= ln && s - ln < nt && blk < nblk;
-                // ---- one column of the block (Hyyro's formulation, as gasm_host::levenshtein)
-                const u64 hm = (ch & 2) ? ~0ull : 0ull, lm = (ch & 1) ? ~0ull : 0ull;
-                u64 eq = ~((H ^ hm) | (L ^ lm)) & valid;
-                const u64 xv = eq | Mv;
-                if (hin < 0) eq |= 1;
-                const u64 xh = (((eq & Pv) + Pv) ^ Pv) | eq;
-                u64 ph = Mv | ~(xh | Pv);
-                u64 mh = Pv & xh;
-                const int ho = (ph & top) ? 1 : ((mh & top) ? -1 : 0);
-                ph <<= 1;
-                mh <<= 1;
-                if (hin < 0) mh |= 1;
-                else if (hin > 0) ph |= 1;
-                if (act) {
-                    Pv = mh | ~(xv | ph);
-                    Mv = ph & xv;
-                    hout = ho;
-                    if (last_band && ln == last_lane) { score += ho; best = score < best ? score : best; }
-                }
-                // ---- the delta leaving the band's last block, column s - 63, parked for the next band
-                if (!last_band && s >= 63) {
-                    const u32 j = s - 63;
+            const bool mine = blk < nblk;
+            const bool scorer = last_band && ln == last_lane;
+            u32 cout = 0;                                         // deltas leaving the band, columns [s0 - 64, s0) of the chunk before
+            // columns in chunks of 64: lane l holds the target code and the incoming delta of column s0 + l; step s of
+            // the chunk takes lane s of them for lane 0 (the straight-line body below has no branch)
+            for (u32 s0 = 0; s0 < nt + 63; s0 += 64) {
+                const u32 jl = s0 + ln;
+                const u32 tch = jl < nt ? (u32)(twords[jl >> 5] >> (62 - 2 * (jl & 31))) & 3u : 0u;
+                const u32 cin = (band && jl < nt) ? (u32)carry[jl] : 1u;
+                const u32 steps = min(64u, nt + 63 - s0);
+                for (u32 t = 0; t < steps; ++t) {
+                    const u32 s = s0 + t;
+                    const int ch_new = (int)__builtin_amdgcn_readlane((int)tch, t);
+                    const int hin_new = band ? (int)__builtin_amdgcn_readlane((int)cin, t) - 1 : hin0;
+                    ch = wave_shr1(ch, ch_new);
+                    const int hin = wave_shr1(hout, hin_new);
+                    const bool act = mine && s >= ln && s - ln < nt;
+                    // ---- one column of the block (Hyyro's formulation, as gasm_host::levenshtein), branch-free
+                    const u64 hm = 0ull - (u64)((ch >> 1) & 1), lm = 0ull - (u64)(ch & 1);
+                    const u64 neg = hin < 0 ? 1ull : 0ull, pos = hin > 0 ? 1ull : 0ull;
+                    const u64 eq0 = ~((H ^ hm) | (L ^ lm)) & valid;
+                    const u64 xv = eq0 | Mv;
+                    const u64 eq = eq0 | neg;
+                    const u64 xh = (((eq & Pv) + Pv) ^ Pv) | eq;
+                    const u64 ph0 = Mv | ~(xh | Pv), mh0 = Pv & xh;
+                    const int ho = (ph0 & top) ? 1 : ((mh0 & top) ? -1 : 0);
+                    const u64 ph = (ph0 << 1) | pos, mh = (mh0 << 1) | neg;
+                    const u64 nPv = mh | ~(xv | ph), nMv = ph & xv;
+                    Pv = act ? nPv : Pv;
+                    Mv = act ? nMv : Mv;
+                    hout = act ? ho : hout;
+                    score += (act && scorer) ? ho : 0;
+                    best = score < best ? score : best;
+                    // ---- the delta leaving the band's last block belongs to column s - 63
                     const int h63 = __builtin_amdgcn_readlane(hout, 63);
-                    if (ln == (j & 63)) cout = (u32)(h63 + 1);
-                    if ((j & 63) == 63 || j + 1 == nt) {
-                        const u32 jj = (j & ~63u) + ln;
+                    cout = ln == ((s - 63) & 63) ? (u32)(h63 + 1) : cout;
+                    if (!last_band && s >= 63 && (((s - 63) & 63) == 63 || s - 62 == nt)) {     // uniform: once per 64 columns
+                        const u32 jj = ((s - 63) & ~63u) + ln;
                         if (jj < nt) carry[jj] = (u8)cout;
                     }
                 }
