@@ -71,8 +71,8 @@ __global__ void k_pack_ascii(const u8* ascii, u64 nbases, u64* words, u64 nwords
 #define GASM_TILE_WG 512     // threads of a tile workgroup (k_tile_hist, k_bucket_scatter)
 template <class K> __global__ void k_tile_hist(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 n_tiles, ushort4* tcnt);
 __global__ void k_tile_scan(ReadSet rs, int bbits, u32 padm, const ushort4* tcnt, u32* toff, u32* hist);
-template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n, const u32* tail, u32* report, u32 stride, u32 count);
-__global__ void k_seg_offsets(const u32* seg_ncontig, const u64* seg_cbases, u32 S, u32* seg_cstart, u64* seg_bstart, u32* report);
+template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n, const u32* tail, u32* report, u32 stride, u32 count, u32 ticket);
+__global__ void k_seg_offsets(const u32* seg_ncontig, const u64* seg_cbases, u32 S, u32* seg_cstart, u64* seg_bstart, u32* report, u32 ticket);
 __global__ void k_copy_u64(const u64* a, u64* b, u32 n);
 template <class K>
 __global__ void k_bucket_scatter(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 padm, u32 n_tiles, const u64* bstart, const u32* toff,

@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 p
 // `tail` — what the host needs after its wait, without a copy engine in between.
 template <class TO>
 __global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, TO* __restrict__ out, u32 n, const u32* __restrict__ tail,
-                                                    u32* __restrict__ report, u32 stride, u32 count) {
+                                                    u32* __restrict__ report, u32 stride, u32 count, u32 ticket) {
     __shared__ u32 s_tmp[16];
     TO carry = 0;
     for (u32 base = 0; base < n; base += 1024) {
@@ -191,15 +191,20 @@ __global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, 
         __syncthreads();          // the outputs were written by this workgroup
         for (u32 i = threadIdx.x; i <= count; i += 1024) report[i] = (u32)out[(u64)i * stride];
         if (threadIdx.x == 0) report[count + 1] = tail ? *tail : 0u;
+        // the ticket goes last: the host spins on it instead of sleeping in a stream wait
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) { __threadfence_system(); report[count + 2] = ticket; }
     }
 }
-template __global__ void k_scan_excl<u64>(const u32*, u64*, u32, const u32*, u32*, u32, u32);
-template __global__ void k_scan_excl<u32>(const u32*, u32*, u32, const u32*, u32*, u32, u32);
+template __global__ void k_scan_excl<u64>(const u32*, u64*, u32, const u32*, u32*, u32, u32, u32);
+template __global__ void k_scan_excl<u32>(const u32*, u32*, u32, const u32*, u32*, u32, u32, u32);
 
 // Exclusive scans of the per-segment contig counts and bases (k_contig_scan) into the segment directories, on the
 // device and, for the host, in pinned memory: [0, S] contig starts, then [S + 1, 2S + 1] base starts as (lo, hi) pairs.
 __global__ void __launch_bounds__(64) k_seg_offsets(const u32* __restrict__ seg_ncontig, const u64* __restrict__ seg_cbases, u32 S,
-                                                    u32* __restrict__ seg_cstart, u64* __restrict__ seg_bstart, u32* __restrict__ report) {
+                                                    u32* __restrict__ seg_cstart, u64* __restrict__ seg_bstart, u32* __restrict__ report,
+                                                    u32 ticket) {
     // one wave, 64 segments at a time (a batch rarely has more than a few hundred segments)
     const u32 ln = threadIdx.x;
     u32 ccarry = 0;
@@ -230,6 +235,8 @@ __global__ void __launch_bounds__(64) k_seg_offsets(const u32* __restrict__ seg_
         report[S] = ccarry;
         report[S + 1 + 2 * S] = (u32)bcarry; report[S + 2 + 2 * S] = (u32)(bcarry >> 32);
     }
+    __threadfence_system();                    // (one wave: every lane's report words are out before lane 0's ticket)
+    if (ln == 0) report[3 * S + 3] = ticket;
 }
 
 // ================================================================================================================

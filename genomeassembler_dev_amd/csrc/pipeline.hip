@@ -1,5 +1,7 @@
 // pipeline.hip — host orchestration of the device pipeline.  All launches go to the ctx stream; the host only waits
 // where a size is needed to allocate the next stage (distinct count, contig bytes) and at fetch time.
+#include <atomic>
+#include <chrono>
 #include "pipeline.h"
 
 #include <algorithm>
@@ -41,6 +43,21 @@ struct Knobs {
     }
 };
 static const Knobs& knobs() { static const Knobs k; return k; }
+
+// Wait for a report a kernel writes into pinned host memory: the kernel's last store is `ticket` at `word`.  Spinning on
+// that word costs a few microseconds; waking up from hipStreamSynchronize costs 15-20 us (more on a busy host) — twice
+// per build, with the GPU idle meanwhile.  After ~2 ms of spinning (a large batch) the thread sleeps in the stream wait.
+static int wait_report(gasm_ctx* ctx, const volatile u32* word, u32 ticket) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (u32 spin = 0;; ++spin) {
+        if (*word == ticket) { std::atomic_thread_fence(std::memory_order_acquire); return GASM_OK; }
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (*word != ticket) { gasm_set_error("a kernel finished without writing its report"); return GASM_ERR_HIP; }
+    return GASM_OK;
+}
+static u32 next_ticket() { static std::atomic<u32> t{1}; u32 v = t.fetch_add(1); return v ? v : t.fetch_add(1); }
 
 // grid of the segment-major kernels (seg_chunk, device_utils.h): 8 x chunks x ceil(S / 8) workgroups
 static dim3 seg_grid(u32 chunks, u32 S) { return dim3(8u * chunks * ((S + 7u) / 8u)); }
@@ -352,7 +369,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         }
         GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(1024), 0, rs, bbits, padm, bs.d_cube.as<ushort4>(),
                 bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
-        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr, (u32*)nullptr, 0u, 0u);
+        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr, (u32*)nullptr, 0u, 0u, 0u);
         const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
         // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
         const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
@@ -399,11 +416,12 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         }
         // the scan reports the segments' first entries and the overflow flag straight into pinned host memory: one wait,
         // no copy engine
-        if ((size_t)S + 2 > ctx->h_pin_words * 2) { gasm_set_error("too many segments for the report buffer"); return GASM_ERR_CAPACITY; }
+        if ((size_t)S + 3 > ctx->h_pin_words * 2) { gasm_set_error("too many segments for the report buffer"); return GASM_ERR_CAPACITY; }
         u32* const h_rep = reinterpret_cast<u32*>(ctx->h_pin);
+        const u32 ticket = next_ticket();
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt, bs.d_flags.as<u32>(),
-                h_rep, nb, S);
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+                h_rep, nb, S, ticket);
+        GCHK(wait_report(ctx, h_rep + S + 2, ticket));
         bs.h_dstart.assign(h_rep, h_rep + S + 1);       // first distinct k-mer of every segment (+ the total)
         if (!h_rep[S + 1]) break;
         if (small_tbl && W == 1) { small_tbl = false; continue; }   // same partition, larger tables
@@ -494,14 +512,15 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     GLAUNCH(ctx, "k_contig_scan", k_contig_scan, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
             bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), d_seg_ncontig, bs.d_seg_cbases.as<u64>());
     // segment directories of the contigs: scanned on the device, reported through pinned host memory (one wait, no copies)
-    if (3 * (size_t)S + 3 > ctx->h_pin_words * 2) { gasm_set_error("too many segments for the report buffer"); return GASM_ERR_CAPACITY; }
+    if (3 * (size_t)S + 4 > ctx->h_pin_words * 2) { gasm_set_error("too many segments for the report buffer"); return GASM_ERR_CAPACITY; }
     GCHK(bs.d_seg_cstart.ensure(((size_t)S + 1) * 4));
     GCHK(bs.d_seg_bstart.ensure(((size_t)S + 1) * 8));
     {
         u32* const h_rep = reinterpret_cast<u32*>(ctx->h_pin);
+        const u32 ticket = next_ticket();
         GLAUNCH(ctx, "k_seg_offsets", k_seg_offsets, dim3(1), dim3(64), 0, d_seg_ncontig, bs.d_seg_cbases.as<u64>(), S, bs.d_seg_cstart.as<u32>(),
-                bs.d_seg_bstart.as<u64>(), h_rep);
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+                bs.d_seg_bstart.as<u64>(), h_rep, ticket);
+        GCHK(wait_report(ctx, h_rep + 3 * (size_t)S + 3, ticket));
         for (u32 s = 0; s <= S; ++s) {
             bs.h_seg_cstart[s] = h_rep[s];
             bs.h_seg_bstart[s] = (u64)h_rep[S + 1 + 2 * s] | ((u64)h_rep[S + 2 + 2 * s] << 32);
