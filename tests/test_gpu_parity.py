@@ -278,6 +278,32 @@ def test_levenshtein_kernel_against_oracle(qtable):
     assert m["lev_dist_vs_true"].tolist() == [orc.levenshtein(p, t2) for p in paths[2:6]]
 
 
+def test_batch_score_without_the_graph_shortcut(qtable):
+    """ragged reads, some shorter than k and some empty: the batch scorer cannot use "a read starts with a k-mer of the
+    graph" and takes the general path (reads indexed, paths scanned, first occurrence per (path, read)) with several
+    segments at once"""
+    keys, prob = qtable
+    rng = np.random.default_rng(8)
+    k = 15
+    segs, genomes = [], []
+    for s in range(4):
+        g = _strs(synth.make_segment(400 + s, 2500, planted=(s % 2 == 0))[None, :])[0]
+        rs = [g[a:a + int(rng.integers(6, 70))] for a in rng.integers(0, 2430, 700)]
+        rs += ["", rs[0], rs[1]] if s != 2 else []
+        segs.append(rs)
+        genomes.append(g)
+    b = ga.SegmentBatch.from_strings(segs)
+    b.build(k).score(8, prob)
+    contigs, sc = b.contigs(), b.scores()
+    for s, rs in enumerate(segs):
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+        assert contigs[s] == ref["contigs"]
+        o = orc.calc_breakscore(contigs[s], rs, genomes[s], 8, keys, prob, with_lev=False, with_freq=False)
+        a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+        _check_scores({kk: v[a:e] for kk, v in sc.items() if kk != "seg_contig_off"}, o, with_lev=False)
+    b.close()
+
+
 # ------------------------------------------------------------------------------------------------ calc_breakscore
 def _score_case(seed, L=1200, rl=20, cov=40, k=15):
     g = synth.make_segment(seed, L, n_short=3, short_len=60, n_long=1, long_len=150, tandem_len=60, planted=True)
