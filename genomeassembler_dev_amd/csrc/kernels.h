@@ -95,7 +95,8 @@ __global__ void k_chain_len(const u8* eflag, const u32* nxt, const u64* link, u3
 __global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u32* e_cid, u64* e_coff, u32* seg_ncontig,
                               u64* seg_cbases);
 __global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* clen, const u32* seg_cstart,
-                               const u64* seg_bstart, u32* e_cid, u64* e_coff, u64* c_off, u32 n_segments, u32 chunks);
+                               const u64* seg_bstart, u32* e_cid, u64* e_coff, u64* c_off, u32 n_segments, u32 chunks, u32 n_contigs,
+                               u64 contig_bases);
 template <class K>
 __global__ void k_contig_emit(GraphView gv, const u8* eflag, const u64* link, const u64* e_coff, u8* out, u32 n_segments, u32 chunks);
 

@@ -1038,7 +1038,9 @@ __global__ void __launch_bounds__(1024) k_contig_scan(GraphView gv, const u8* __
 __global__ void __launch_bounds__(GASM_WG) k_contig_place(GraphView gv, const u8* __restrict__ eflag, const u32* __restrict__ clen,
                                                           const u32* __restrict__ seg_cstart, const u64* __restrict__ seg_bstart,
                                                           u32* __restrict__ e_cid, u64* __restrict__ e_coff,
-                                                          u64* __restrict__ c_off, u32 n_segments, u32 chunks) {
+                                                          u64* __restrict__ c_off, u32 n_segments, u32 chunks, u32 n_contigs,
+                                                          u64 contig_bases) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) c_off[n_contigs] = contig_bases;      // end of the last contig
     u32 seg, chunk;
     if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
     const u32 nb = 1u << gv.bbits;

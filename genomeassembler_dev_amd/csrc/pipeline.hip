@@ -533,9 +533,11 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     GCHK(bs.d_contig_ascii.ensure(bs.contig_bases + 64));
     if (bs.n_contigs) {
         GLAUNCH(ctx, "k_contig_place", k_contig_place, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
-                bs.d_seg_cstart.as<u32>(), bs.d_seg_bstart.as<u64>(), bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_c_off.as<u64>(), S, dchunks);
+                bs.d_seg_cstart.as<u32>(), bs.d_seg_bstart.as<u64>(), bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_c_off.as<u64>(), S, dchunks,
+                bs.n_contigs, bs.contig_bases);
+    } else {
+        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, ctx->stream, bs.d_c_off.as<u64>(), bs.contig_bases);
     }
-    hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, ctx->stream, bs.d_c_off.as<u64>() + bs.n_contigs, bs.contig_bases);
     if (bs.n_contigs) {
         if (W == 1) {
             GLAUNCH(ctx, "k_contig_emit", k_contig_emit<u64>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
