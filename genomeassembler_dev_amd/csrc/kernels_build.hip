@@ -8,10 +8,14 @@
 //   k_bucket_scatter  lib/DeNovoAssembler.R:109-130 (every k-mer of every read) fused with the first half of the
 //                     de-duplication that lib/DeNovoAssembler.cpp:104-122 does through its hash map
 //   k_bucket_dedup    lib/DeNovoAssembler.cpp:104-122 (distinct edges) + multiplicities
-//   k_node_flags      lib/DeNovoAssembler.cpp:125-169 (in/out degree over distinct edges, branching nodes)
+//   k_edge_target / k_edge_multi / k_node_flags
+//                     lib/DeNovoAssembler.cpp:125-169 (in/out degree over distinct edges, branching nodes)
 //   k_edge_next       lib/DeNovoAssembler.cpp:172-189, one step of the walk: successor edge or stop
-//   k_link_jump       the walk itself as pointer doubling (the reference walks node by node)
-//   k_chain_len / k_contig_scan / k_contig_place / k_contig_emit
+//   k_rank_rulers / k_rank_lds / k_link_jump
+//                     the walk itself as list ranking (the reference walks node by node): every second edge ranked by
+//                     pointer doubling inside LDS, the rest finished by a step or two; whole-GPU doubling for
+//                     segments of more than 65534 edges
+//   k_chain_len / k_contig_scan / k_seg_offsets / k_contig_place / k_contig_emit
 //                     lib/DeNovoAssembler.cpp:183-192: contig text, in sorted order (contigs start with distinct
 //                     k-mers, so sorting contigs = sorting their first edges)
 #include "device_utils.h"
