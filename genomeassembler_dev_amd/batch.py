@@ -45,6 +45,20 @@ class SegmentBatch:
         buf = np.frombuffer(b"".join(data), dtype=np.uint8) if data else np.zeros(0, dtype=np.uint8)
         return cls(buf, seg, read_off=np.array(off, dtype=np.uint64), ctx=ctx)
 
+    @classmethod
+    def from_fastq(cls, paths, non_acgt="drop", ctx=None):
+        """one FASTQ/FASTA file (plain or .gz) per segment; reads with a base outside ACGT are dropped (count in
+        `.dropped_reads`) or, with non_acgt='error', refused"""
+        from . import seqio
+        reads, off, seg, dropped = seqio.segments_from_files(paths, non_acgt=non_acgt)
+        lens = np.diff(off)
+        if lens.size and (lens == lens[0]).all() and lens[0] > 0:
+            b = cls(reads, seg, fixed_len=int(lens[0]), ctx=ctx)
+        else:
+            b = cls(reads, seg, read_off=off, ctx=ctx)
+        b.dropped_reads = dropped
+        return b
+
     def build(self, k, genome_len_hint=0):
         check(lib().gasm_batch_build(self.h, int(k), int(genome_len_hint)))
         self.k = int(k)

@@ -278,6 +278,37 @@ def test_levenshtein_kernel_against_oracle(qtable):
     assert m["lev_dist_vs_true"].tolist() == [orc.levenshtein(p, t2) for p in paths[2:6]]
 
 
+def test_batch_from_fastq_files(tmp_path, qtable):
+    """FASTQ in (one file per segment, one of them gzipped FASTA, a read with an N dropped) -> the same contigs and
+    scores as the same reads handed over as strings"""
+    import gzip
+    keys, prob = qtable
+    segs, paths = [], []
+    for s in range(2):
+        g = synth.make_segment(500 + s, 3000, planted=True)
+        rs = _strs(synth.simulate_reads(g, 60, 25, 600 + s))
+        segs.append(rs)
+        if s == 0:
+            p = tmp_path / "s0.fastq"
+            p.write_text("".join(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" for i, r in enumerate(rs)) + "@bad\nACGTNACGT\n+\nIIIIIIIII\n")
+        else:
+            p = tmp_path / "s1.fa.gz"
+            with gzip.open(p, "wb") as f:
+                f.write("".join(f">r{i}\n{r[:30]}\n{r[30:]}\n" for i, r in enumerate(rs)).encode())
+        paths.append(p)
+    a = ga.SegmentBatch.from_fastq(paths)
+    b = ga.SegmentBatch.from_strings(segs)
+    assert a.dropped_reads == 1
+    a.build(21).score(8, prob)
+    b.build(21).score(8, prob)
+    assert a.contigs() == b.contigs()
+    sa, sb = a.scores(), b.scores()
+    for kk in sa:
+        assert np.array_equal(np.nan_to_num(np.asarray(sa[kk])), np.nan_to_num(np.asarray(sb[kk]))), kk
+    a.close()
+    b.close()
+
+
 def test_batch_score_without_the_graph_shortcut(qtable):
     """ragged reads, some shorter than k and some empty: the batch scorer cannot use "a read starts with a k-mer of the
     graph" and takes the general path (reads indexed, paths scanned, first occurrence per (path, read)) with several
