@@ -63,7 +63,15 @@ __device__ __forceinline__ u32 kfield(const K128& a, int s) { return (u32)kshr(a
 __device__ __forceinline__ u32 klow2(u64 a) { return (u32)a & 3u; }
 __device__ __forceinline__ u32 klow2(const K128& a) { return (u32)a.lo & 3u; }
 
-__device__ __forceinline__ u32 khash(u64 a) { return hash64(a); }
+// Home-set hash of the de-duplication tables.  A 64-bit multiply is a handful of quarter-rate 32-bit multiplies on CDNA —
+// a third of the vector time of k_bucket_dedup; two 24-bit multiplies (full rate) over a folded key spread real k-mer
+// sets just as evenly (same overflow fraction on random keys, genome buckets and two-letter sequences).
+__device__ __forceinline__ u32 khash(u64 a) {
+    const u32 lo = (u32)a, hi = (u32)(a >> 32);
+    u32 x = lo ^ __builtin_amdgcn_alignbit(hi, hi, 19);      // lo ^ rotl(hi, 13)
+    x ^= x >> 17;
+    return __umul24(x, 0xB5297Au) ^ __umul24(x >> 8, 0x68E31Du);
+}
 __device__ __forceinline__ u32 khash(const K128& a) { return hash64(a.lo ^ (a.hi * 0xD6E8FEB86659FD93ull)); }
 
 // ---- windows of a packed base stream
