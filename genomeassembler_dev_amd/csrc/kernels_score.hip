@@ -3,9 +3,10 @@
 // The reference scores a path by, for every unique read, std::string::find(read) in the path (first occurrence
 // only), turning the hit position into an octamer window and accumulating count x probability
 // (lib/DeNovoAssembler.cpp:346-426).  Same results, different route:
-//   k_seed_insert  hash index of every path position by its first w bases (w = min(32, shortest read))
-//   k_read_match   one thread per read: candidates from the index in increasing position order, full 2-bit
-//                  compare, first hit per path -> integer counters per path position (:360, :389-390)
+//   k_read_insert / k_path_scan / k_first_to_poscnt
+//                  the reads indexed by their first w bases (w = min(32, shortest read)); one thread per path position
+//                  looks its window up, compares in full and keeps the first occurrence per (path, read); the first
+//                  occurrences become the position counters (lib/DeNovoAssembler.cpp:346-392: first find() per path)
 //   k_path_reduce  per path: sum over positions of count x prob(window(position)) in a fixed order (:394-426)
 // Reads are not de-duplicated first: the reference does that (:334-337) only to save work, a read occurring c times
 // adds c to the same counter either way.

@@ -55,7 +55,7 @@ struct BuildState {
     std::vector<u32> h_dstart;              // n_segments*nb+1
     std::vector<u32> h_seg_cstart;          // n_segments+1
     std::vector<u64> h_seg_bstart;          // n_segments+1
-    DBuf d_keys, d_mult, d_hist, d_tcnt, d_cube, d_fdir, d_bstart, d_cursor, d_bucket_d, d_dstart, d_flags, d_rtab;
+    DBuf d_keys, d_mult, d_hist, d_toff, d_tcnt, d_fdir, d_bstart, d_cursor, d_bucket_d, d_dstart, d_flags, d_rtab;
     DBuf d_dk_key, d_dk_cnt, d_eflag, d_nxt, d_link, d_clen, d_ecid, d_ecoff;
     DBuf d_seg_cbases, d_seg_cstart, d_seg_bstart, d_c_off, d_contig_ascii;
     // host copies filled by fetch

@@ -249,7 +249,7 @@ PathSet DevPaths::view() const {
 void DevPaths::release() { d_words.release(); d_p_off.release(); d_seg_path_off.release(); d_seg_base_off.release(); }
 
 void BuildState::release() {
-    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_tcnt, &d_cube, &d_fdir, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
+    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_toff, &d_tcnt, &d_fdir, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
                     &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_seg_cbases, &d_seg_cstart,
                     &d_seg_bstart, &d_c_off, &d_contig_ascii})
         b->release();
@@ -298,7 +298,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     const u32 orr = std::max(1u, (nk_max + g * KT - 1) / (g * KT));
     if (orr > 0xFFFFu) { gasm_set_error("reads longer than %u bases are not supported", GASM_TILE_WG * KT * 0xFFFFu); return GASM_ERR_CAPACITY; }
     GCHK(rd.set_tiles(ctx, ipt, orr));
-    // bucket bits: aim at <= ~900 distinct k-mers per bucket (2048-slot LDS table in 4-slot sets, limit 1408)
+    // bucket bits: aim at <= ~900 distinct k-mers per bucket (2048-slot LDS table in two-slot sets, limit 1408)
     const int bb_cap = std::min(10, 2 * (k - 1));
     int bbits = 0;
     {
@@ -350,11 +350,11 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         const u32 nb = 1u << bbits, padm = pad_mask(nb);
         nbt = S * nb;
         GCHK(bs.d_hist.ensure((size_t)nbt * 4));
-        GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 4));
+        GCHK(bs.d_toff.ensure((size_t)rd.n_tiles * nb * 4));
         const u64 n_alloc = N + (u64)padm * rd.n_tiles * nb;
         GCHK(bs.d_keys.ensure((n_alloc + SCRATCH_KEYS) * KB));
         GCHK(bs.d_mult.ensure(n_alloc * 4));
-        GCHK(bs.d_cube.ensure((size_t)rd.n_tiles * nb * 8 + 64));      // four 16-bit sub-counts per (tile, bucket)
+        GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 8 + 64));      // four 16-bit sub-counts per (tile, bucket)
         GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
         GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
@@ -362,23 +362,23 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 256, ctx->stream));
         if (W == 1) {
             GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
-                    bs.d_cube.as<ushort4>());
+                    bs.d_tcnt.as<ushort4>());
         } else {
             GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
-                    bs.d_cube.as<ushort4>());
+                    bs.d_tcnt.as<ushort4>());
         }
-        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(1024), 0, rs, bbits, padm, bs.d_cube.as<ushort4>(),
-                bs.d_tcnt.as<u32>(), bs.d_hist.as<u32>());
+        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(1024), 0, rs, bbits, padm, bs.d_tcnt.as<ushort4>(),
+                bs.d_toff.as<u32>(), bs.d_hist.as<u32>());
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr, (u32*)nullptr, 0u, 0u, 0u);
         const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
         // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
         const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
         if (W == 1) {
             GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<ushort4>(), bs.d_keys.as<u64>(), n_alloc);
+                    bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<u64>(), n_alloc);
         } else {
             GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_tcnt.as<u32>(), bs.d_cube.as<ushort4>(), bs.d_keys.as<K128>(), n_alloc);
+                    bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<K128>(), n_alloc);
         }
         unsigned long long* d_stamps = nullptr;
         static DBuf stamp_buf;
