@@ -25,11 +25,12 @@ __global__ void k_add_empty_reads(PathSet ps, const u64* __restrict__ seg_empty,
 
 // Tuning / diagnostic knobs, read from the environment once (none changes results except GASM_DBG_DEDUP, an ablation):
 //   GASM_DEDUP_TBL=2048|4096   force the de-duplication table size        GASM_SCATTER_WGS=n   scatter workgroups per CU (8)
+//   GASM_HIST_WGS=n            histogram workgroups per CU (64)
 //   GASM_DBG_PADM=m            cap the run padding at m + 1 keys          GASM_RANK_GLOBAL=1   whole-GPU list ranking only
 //   GASM_DBG_RANK_ROUNDS=n     cap the LDS ranking rounds (ablation)      GASM_DBG_DEDUP=1|2   loads only / no ordering (ablation)
 //   GASM_DBG_STAMPS=file       per-phase clock stamps of k_bucket_dedup to stderr and `file`
 struct Knobs {
-    int dedup_tbl = 0, dbg_dedup = 0, padm = -1, scatter_wgs = 8, rank_rounds = 18;
+    int dedup_tbl = 0, dbg_dedup = 0, padm = -1, scatter_wgs = 8, hist_wgs = 64, rank_rounds = 18;
     bool rank_global = false;
     const char* stamps = nullptr;
     Knobs() {
@@ -37,6 +38,7 @@ struct Knobs {
         if (const char* v = getenv("GASM_DBG_DEDUP")) dbg_dedup = atoi(v);
         if (const char* v = getenv("GASM_DBG_PADM")) padm = atoi(v);
         if (const char* v = getenv("GASM_SCATTER_WGS")) scatter_wgs = std::max(1, atoi(v));
+        if (const char* v = getenv("GASM_HIST_WGS")) hist_wgs = std::max(1, atoi(v));
         if (const char* v = getenv("GASM_DBG_RANK_ROUNDS")) rank_rounds = atoi(v);
         rank_global = getenv("GASM_RANK_GLOBAL") != nullptr;
         stamps = getenv("GASM_DBG_STAMPS");
@@ -343,7 +345,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         return m;
     };
     const ReadSet rs = rd.view();
-    const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * 8);
+    const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().hist_wgs);
     constexpr u32 SCRATCH_KEYS = 1024 * (GASM_TILE_WG / 64) * 64 * 2;   // 16 bytes per lane and wave of 1024 workgroup slots (k_bucket_scatter)
     u32 nbt = 0;
     while (true) {
