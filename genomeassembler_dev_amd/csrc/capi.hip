@@ -201,7 +201,26 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
             }
         }
         bool lev_done = false;
-        if ((flags & GASM_WANT_LEV) && !getenv("GASM_LEV_HOST")) {
+        // GPU or host?  One wave walks a path's bands column by column (~0.25 us per column and band, whatever the number
+        // of paths up to a few thousand), the host routine costs ~1.5 ns per 64 cells and runs 32 paths at a time: a
+        // handful of contigs is quicker on the host, thousands of scaffolds 10-60x quicker on the GPU.
+        bool lev_gpu = !getenv("GASM_LEV_HOST");
+        if (lev_gpu && !getenv("GASM_LEV_GPU") && (flags & GASM_WANT_LEV)) {
+            u64 max_bands = 0;
+            double cells = 0;
+            for (u64 p = 0; p < n_paths; ++p) {
+                const u64 nq = path_off[p + 1] - path_off[p];
+                max_bands = std::max<u64>(max_bands, (nq + 4095) / 4096);
+                cells += (double)nq * (double)true_len;
+            }
+            // measured: 0.24 us per column and band for a wave alone on its SIMD, 0.58 us with four waves per SIMD
+            const double per_simd = (double)n_paths / 1024.0;
+            const double share = std::max(1.0, 0.6 * std::min(per_simd, 4.0)), rounds = std::max(1.0, per_simd / 4.0);
+            const double gpu_ms = 0.05 + (double)max_bands * (double)(true_len + 63) * 0.00024 * share * rounds;
+            const double host_ms = cells / 64.0 * 1.5e-6 / (double)std::max<u64>(1, std::min<u64>(32, n_paths));
+            lev_gpu = gpu_ms < host_ms;
+        }
+        if ((flags & GASM_WANT_LEV) && lev_gpu) {
             // lib/DeNovoAssembler.cpp:463 (global) / lib/BreakageScorer.cpp:339 (infix): one wave per path on the GPU
             st = pipeline_levenshtein(ctx, dp, true_solution, true_len, velvet, s->lev, &lev_done);
         }

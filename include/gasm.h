@@ -106,9 +106,10 @@ void gasm_strlist_free(gasm_strlist* s);
  *   variant GASM_SCORE_OWN    replaces lib/DeNovoAssembler.cpp:317-477  (returns path_freq)
  *   variant GASM_SCORE_VELVET replaces lib/BreakageScorer.cpp:186-353   (returns path_prob_dist(+_startpos),
  *                                                                         Levenshtein in infix mode)
- * flags: GASM_WANT_LEV computes lev_dist_vs_true (else zeros) on the GPU — global distance for the own variant, infix for
- *        the velvet one, as the reference's two calc_levenshtein do; a true_solution with bytes outside ACGT falls back to
- *        the host routine; GASM_WANT_FREQ materialises the dense path_freq
+ * flags: GASM_WANT_LEV computes lev_dist_vs_true (else zeros) — global distance for the own variant, infix for the velvet
+ *        one, as the reference's two calc_levenshtein do; on the GPU when that is the quicker place (many or long paths),
+ *        on the host for a handful of short ones or a true_solution with bytes outside ACGT (same numbers either way;
+ *        GASM_LEV_GPU / GASM_LEV_HOST in the environment force one or the other); GASM_WANT_FREQ materialises the dense path_freq
  * (n_paths x n_table doubles, in bp_kmer order — the reference emits them in hash-iteration order, so only the
  * multiset per path is defined there).
  * bp_kmer keys must be distinct ACGT strings of length 1..8 (the reference tables hold lengths 2,4,6,8).

@@ -14,6 +14,8 @@ PL = int(args[1]) if len(args) > 1 else 40000
 TL = int(args[2]) if len(args) > 2 else 50000
 if "--host" in sys.argv:
     os.environ["GASM_LEV_HOST"] = "1"
+else:
+    os.environ["GASM_LEV_GPU"] = "1"       # measure the kernel whatever the library's own GPU/host choice would be
 
 import genomeassembler_dev_amd as ga  # noqa: E402
 from genomeassembler_dev_amd import qtable, synth  # noqa: E402
