@@ -107,7 +107,8 @@ struct SeedTable {
     const u64* tbl_off;   // n_segments+1 slot offsets; every segment's table size is a power of two
 };
 __global__ void k_read_insert(ReadSet rs, SeedTable st, int w);
-__global__ void k_path_scan(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, const u64* first_off, u32* first);
+__global__ void k_path_scan(ReadSet rs, PathSet ps, SeedTable st, const u64* seg_base_off, int w, const u64* first_off, u32* first, u32 seg0,
+                            u32 path_lo, u32 path_hi);
 __global__ void k_first_to_poscnt(const u32* first, u64 n, u32* poscnt);
 template <class K>
 __global__ void k_score_reads_graph(ReadSet rs, GraphView gv, const u64* link, const u32* e_cid, PathSet ps, const long long* dfix,

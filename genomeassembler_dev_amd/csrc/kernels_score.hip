@@ -88,14 +88,18 @@ __device__ __forceinline__ bool bases_equal(const u64* __restrict__ aw, u64 a0, 
 
 // first[first_off[seg] + (path - first path of seg) * reads of seg + (read - first read of seg)] = smallest global base
 // position at which the read occurs in the path (GASM_NONE32: nowhere)
+// A launch covers all segments (seg0 = 0, path_hi = 0: blockIdx.y = segment, rows at first_off[segment]) or one slice
+// [path_lo, path_hi) of the paths of segment seg0 (rows from 0): the host slices when paths x reads would not fit.
 __global__ void __launch_bounds__(GASM_WG) k_path_scan(ReadSet rs, PathSet ps, SeedTable st, const u64* __restrict__ seg_base_off, int w,
-                                                       const u64* __restrict__ first_off, u32* __restrict__ first) {
+                                                       const u64* __restrict__ first_off, u32* __restrict__ first, u32 seg0, u32 path_lo,
+                                                       u32 path_hi) {
     __shared__ u32 s_c0;
-    const u32 seg = blockIdx.y;
-    const u64 lo = seg_base_off[seg], hi = seg_base_off[seg + 1];
+    const u32 seg = seg0 + blockIdx.y;
+    const bool slice = path_hi != 0;
+    const u64 lo = slice ? ps.p_off[path_lo] : seg_base_off[seg], hi = slice ? ps.p_off[path_hi] : seg_base_off[seg + 1];
     const u64 g0 = lo + (u64)blockIdx.x * GASM_WG;
     if (g0 >= hi) return;
-    const u32 pfirst = ps.seg_path_off[seg], plast = ps.seg_path_off[seg + 1];
+    const u32 pfirst = slice ? path_lo : ps.seg_path_off[seg], plast = slice ? path_hi : ps.seg_path_off[seg + 1];
     if (threadIdx.x == 0) s_c0 = pfirst + upper_seg<u64>(ps.p_off + pfirst, plast - pfirst, g0);   // path of the block's first base
     __syncthreads();
     const u64 g = g0 + threadIdx.x;
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(GASM_WG) k_path_scan(ReadSet rs, PathSet ps, S
     const u64 tb = st.tbl_off[seg];
     const u32 mask = (u32)(st.tbl_off[seg + 1] - tb) - 1;
     const u64 rfirst = rs.seg_read_off[seg], nreads = rs.seg_read_off[seg + 1] - rfirst;
-    u32* const row = first + first_off[seg] + (u64)(c - pfirst) * nreads;
+    u32* const row = first + (slice ? 0ull : first_off[seg]) + (u64)(c - pfirst) * nreads;
     for (u32 h = hash64(seed) & mask;; h = (h + 1) & mask) {
         const u32 r = st.gpos[tb + h];
         if (r == GASM_NONE32) break;

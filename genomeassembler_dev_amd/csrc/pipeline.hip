@@ -797,28 +797,50 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
             max_bases = std::max(max_bases, nbases);
             max_reads = std::max(max_reads, nreads);
         }
-        if (foff[S] > (8ull << 30)) {
-            gasm_set_error("paths x reads = %llu first-occurrence entries (more than 2^33): score the paths in several calls", (unsigned long long)foff[S]);
-            return GASM_ERR_CAPACITY;
-        }
+        // the dense first-occurrence table holds paths x reads words: at most `budget` of them at a time, else the paths of
+        // a segment are scored slice by slice (the read table is built once)
+        const u64 budget = getenv("GASM_DBG_FIRST_BUDGET") ? (u64)atoll(getenv("GASM_DBG_FIRST_BUDGET")) : (2ull << 30);
+        const bool sliced = foff[S] > budget;
+        if (sliced && dp.h_p_off.size() != (size_t)P + 1) { gasm_set_error("paths x reads too large for one pass and the path offsets are not on the host"); return GASM_ERR_CAPACITY; }
         if (rd.n_reads > 0xFFFFFFF0ull || TB > 0xFFFFFFF0ull) { gasm_set_error("too many reads or path bases for 32-bit indices"); return GASM_ERR_CAPACITY; }
         GCHK(h2d(ctx, ss.d_tbl_off, toff.data(), toff.size() * 8));
         GCHK(h2d(ctx, ss.d_first_off, foff.data(), foff.size() * 8));
         GCHK(ss.d_seed.ensure(toff[S] * 8));
         GCHK(ss.d_gpos.ensure(toff[S] * 4));
-        GCHK(ss.d_first.ensure(foff[S] * 4 + 16));
         HIPCHK(hipMemsetAsync(ss.d_gpos.p, 0xFF, toff[S] * 4, ctx->stream));
-        HIPCHK(hipMemsetAsync(ss.d_first.p, 0xFF, foff[S] * 4 + 16, ctx->stream));
         SeedTable st;
         st.seed = ss.d_seed.as<u64>();
         st.gpos = ss.d_gpos.as<u32>();
         st.tbl_off = ss.d_tbl_off.as<u64>();
         if (max_bases && max_reads) {
             GLAUNCH(ctx, "k_read_insert", k_read_insert, dim3(ceil_div_u64(max_reads, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), st, w);
-            GLAUNCH(ctx, "k_path_scan", k_path_scan, dim3(ceil_div_u64(max_bases, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), ps, st,
-                    dp.seg_base_off_dev(), w, ss.d_first_off.as<u64>(), ss.d_first.as<u32>());
-            GLAUNCH(ctx, "k_first_to_poscnt", k_first_to_poscnt, dim3(ceil_div_u64(foff[S], GASM_WG)), dim3(GASM_WG), 0, ss.d_first.as<u32>(),
-                    foff[S], ss.d_poscnt.as<u32>());
+            if (!sliced) {
+                GCHK(ss.d_first.ensure(foff[S] * 4 + 16));
+                HIPCHK(hipMemsetAsync(ss.d_first.p, 0xFF, foff[S] * 4 + 16, ctx->stream));
+                GLAUNCH(ctx, "k_path_scan", k_path_scan, dim3(ceil_div_u64(max_bases, GASM_WG), S), dim3(GASM_WG), 0, rd.view(), ps, st,
+                        dp.seg_base_off_dev(), w, ss.d_first_off.as<u64>(), ss.d_first.as<u32>(), 0u, 0u, 0u);
+                GLAUNCH(ctx, "k_first_to_poscnt", k_first_to_poscnt, dim3(ceil_div_u64(foff[S], GASM_WG)), dim3(GASM_WG), 0, ss.d_first.as<u32>(),
+                        foff[S], ss.d_poscnt.as<u32>());
+            } else {
+                for (u32 s = 0; s < S; ++s) {
+                    const u64 nreads = rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s];
+                    const u32 p0 = dp.h_seg_path_off[s], p1 = dp.h_seg_path_off[s + 1];
+                    if (!nreads || p0 == p1) continue;
+                    const u32 step = (u32)std::max<u64>(1, std::min<u64>(budget / nreads, 0x7FFFFFFFull));
+                    for (u32 a = p0; a < p1; a += step) {
+                        const u32 e = (u32)std::min<u64>((u64)a + step, p1);
+                        const u64 entries = (u64)(e - a) * nreads, bases = dp.h_p_off[e] - dp.h_p_off[a];
+                        GCHK(ss.d_first.ensure(entries * 4 + 16));
+                        HIPCHK(hipMemsetAsync(ss.d_first.p, 0xFF, entries * 4 + 16, ctx->stream));
+                        if (bases) {
+                            GLAUNCH(ctx, "k_path_scan", k_path_scan, dim3(ceil_div_u64(bases, GASM_WG), 1), dim3(GASM_WG), 0, rd.view(), ps, st,
+                                    dp.seg_base_off_dev(), w, ss.d_first_off.as<u64>(), ss.d_first.as<u32>(), s, a, e);
+                            GLAUNCH(ctx, "k_first_to_poscnt", k_first_to_poscnt, dim3(ceil_div_u64(entries, GASM_WG)), dim3(GASM_WG), 0,
+                                    ss.d_first.as<u32>(), entries, ss.d_poscnt.as<u32>());
+                        }
+                    }
+                }
+            }
         }
     }
     if (P && rd.n_empty && !use_graph) {

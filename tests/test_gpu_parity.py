@@ -242,6 +242,14 @@ def test_calc_breakscore_scaffold_like_paths(qtable):
         o = orc.calc_breakscore(paths, reads, g, 8, keys, prob, velvet=(variant == "velvet"), with_lev=False,
                                 with_freq=(variant == "own"))
         _check_scores(m, o, with_lev=False)
+    # the same through the sliced form of the first-occurrence table (a budget of 20 paths' worth of entries at a time)
+    os.environ["GASM_DBG_FIRST_BUDGET"] = str(20 * len(reads))
+    try:
+        m2 = ga.calc_breakscore(paths, reads, g, 8, keys, prob, variant="own", with_lev=False, with_freq=False)
+    finally:
+        del os.environ["GASM_DBG_FIRST_BUDGET"]
+    o = orc.calc_breakscore(paths, reads, g, 8, keys, prob, with_lev=False, with_freq=False)
+    _check_scores(m2, o, with_lev=False)
 
 
 def test_levenshtein_kernel_against_oracle(qtable):
