@@ -210,6 +210,19 @@ def test_large_segment_long_reads_and_cycles(qtable):
     o = orc.calc_breakscore(ref["contigs"], rs, "", 8, keys, prob, with_lev=False, with_freq=False)
     _check_scores({kk: v for kk, v in b.scores().items() if kk != "seg_contig_off"}, o, with_lev=False)
     b.close()
+    # (a') a segment that needs all ten bucket bits (1024 buckets: the tile kernels' many-buckets-per-thread paths)
+    g = synth.make_segment(95, 700000, planted=False)
+    reads = synth.simulate_reads(g, 100, 6, 96)
+    rs = _strs(reads)
+    k = 25
+    ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+    b = ga.SegmentBatch(reads.reshape(-1), np.array([0, reads.shape[0]], dtype=np.uint64), fixed_len=100)
+    b.build(k, genome_len_hint=700000)
+    assert len(ref["distinct"]) > 512 * 900
+    assert b.contigs(0) == ref["contigs"]
+    dk, dm = b.distinct_kmers(0)
+    assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist()
+    b.close()
     # (b) + (c): two very long reads, short reads, and a 400-base circle read round and round
     g2 = _strs(synth.make_segment(93, 30000, planted=False)[None, :])[0]
     circ = _strs(synth.make_segment(94, 400, planted=False)[None, :])[0]
