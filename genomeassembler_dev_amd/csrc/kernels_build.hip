@@ -153,24 +153,21 @@ __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 p
     __shared__ u32 s_part[1024];
     const u32 nb = 1u << bbits, seg = blockIdx.x;
     const u32 t0 = rs.seg_tile_start[seg], t1 = rs.seg_tile_start[seg + 1];
-    // the workgroup is `grp` slices of the tile range x min(nb, 1024) buckets: slice sums first, then the offsets
-    const u32 nbw = min(nb, 1024u), grp = 1024u / nbw, sl = threadIdx.x / nbw, bl = threadIdx.x % nbw;
+    // a workgroup = 32 buckets (blockIdx.y) x 32 slices of the segment's tile range: slice sums first, then the offsets
+    const u32 nbw = min(nb, 32u), grp = 1024u / nbw, sl = threadIdx.x / nbw, bl = threadIdx.x % nbw;
     const u32 per = (t1 - t0 + grp - 1) / grp;
     const u32 ta = min(t1, t0 + sl * per), tb = min(t1, ta + per);
-    for (u32 b0 = 0; b0 < nb; b0 += nbw) {
-        const u32 b = b0 + bl;
-        u32 sum = 0;
-        for (u32 t = ta; t < tb; ++t) sum += (sub_total(tcnt[(u64)t * nb + b]) + padm) & ~padm;
-        s_part[threadIdx.x] = sum;
-        __syncthreads();
-        u32 run = 0;
-        for (u32 s = 0; s < sl; ++s) run += s_part[s * nbw + bl];
-        if (sl == grp - 1) hist[(u64)seg * nb + b] = run + sum;
-        __syncthreads();
-        for (u32 t = ta; t < tb; ++t) {
-            toff[(u64)t * nb + b] = run;
-            run += (sub_total(tcnt[(u64)t * nb + b]) + padm) & ~padm;
-        }
+    const u32 b = blockIdx.y * nbw + bl;
+    u32 sum = 0;
+    for (u32 t = ta; t < tb; ++t) sum += (sub_total(tcnt[(u64)t * nb + b]) + padm) & ~padm;
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    u32 run = 0;
+    for (u32 s = 0; s < sl; ++s) run += s_part[s * nbw + bl];
+    if (sl == grp - 1) hist[(u64)seg * nb + b] = run + sum;
+    for (u32 t = ta; t < tb; ++t) {
+        toff[(u64)t * nb + b] = run;
+        run += (sub_total(tcnt[(u64)t * nb + b]) + padm) & ~padm;
     }
 }
 

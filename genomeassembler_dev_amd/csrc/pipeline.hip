@@ -25,12 +25,12 @@ __global__ void k_add_empty_reads(PathSet ps, const u64* __restrict__ seg_empty,
 
 // Tuning / diagnostic knobs, read from the environment once (none changes results except GASM_DBG_DEDUP, an ablation):
 //   GASM_DEDUP_TBL=2048|4096   force the de-duplication table size        GASM_SCATTER_WGS=n   scatter workgroups per CU (8)
-//   GASM_HIST_WGS=n            histogram workgroups per CU (64)
+//   GASM_HIST_WGS=n            histogram workgroups per CU (64)           GASM_DBG_BBITS_ADD=n extra bucket bits (tuning)
 //   GASM_DBG_PADM=m            cap the run padding at m + 1 keys          GASM_RANK_GLOBAL=1   whole-GPU list ranking only
 //   GASM_DBG_RANK_ROUNDS=n     cap the LDS ranking rounds (ablation)      GASM_DBG_DEDUP=1|2   loads only / no ordering (ablation)
 //   GASM_DBG_STAMPS=file       per-phase clock stamps of k_bucket_dedup to stderr and `file`
 struct Knobs {
-    int dedup_tbl = 0, dbg_dedup = 0, padm = -1, scatter_wgs = 8, hist_wgs = 64, rank_rounds = 18;
+    int dedup_tbl = 0, dbg_dedup = 0, padm = -1, scatter_wgs = 8, hist_wgs = 64, rank_rounds = 18, bbits_add = 0;
     bool rank_global = false;
     const char* stamps = nullptr;
     Knobs() {
@@ -39,6 +39,7 @@ struct Knobs {
         if (const char* v = getenv("GASM_DBG_PADM")) padm = atoi(v);
         if (const char* v = getenv("GASM_SCATTER_WGS")) scatter_wgs = std::max(1, atoi(v));
         if (const char* v = getenv("GASM_HIST_WGS")) hist_wgs = std::max(1, atoi(v));
+        if (const char* v = getenv("GASM_DBG_BBITS_ADD")) bbits_add = std::max(0, atoi(v));
         if (const char* v = getenv("GASM_DBG_RANK_ROUNDS")) rank_rounds = atoi(v);
         rank_global = getenv("GASM_RANK_GLOBAL") != nullptr;
         stamps = getenv("GASM_DBG_STAMPS");
@@ -306,6 +307,9 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     {
         const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
         while (bbits < bb_cap && (dest >> bbits) > 900) ++bbits;
+        // few segments: up to two more bits so that there are enough (segment, bucket) workgroups to fill the chip
+        for (int extra = 0; extra < 2 && bbits < bb_cap && ((u64)S << bbits) < 1024; ++extra) ++bbits;
+        bbits = std::min(bb_cap, bbits + knobs().bbits_add);
     }
     GCHK(bs.d_flags.ensure(256));      // [0] bucket overflow, [16..] the list-ranking launches' "still active" words
     bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
@@ -369,7 +373,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
             GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
                     bs.d_tcnt.as<ushort4>());
         }
-        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S), dim3(1024), 0, rs, bbits, padm, bs.d_tcnt.as<ushort4>(),
+        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S, std::max(1u, nb / 32u)), dim3(1024), 0, rs, bbits, padm, bs.d_tcnt.as<ushort4>(),
                 bs.d_toff.as<u32>(), bs.d_hist.as<u32>());
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr, (u32*)nullptr, 0u, 0u, 0u);
         const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
