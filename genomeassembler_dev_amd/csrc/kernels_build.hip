@@ -866,38 +866,42 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
 // even head's own entry is the self-loop (itself, 0).  So "my ancestor is a head" <=> it is odd or its entry loops.
 // ----------------------------------------------------------------------------------------------------------------
 #define GASM_RANK_NONE 0xFFFFFFFFu
-#define GASM_RULER_SHIFT 1            // rulers = edges whose local index is a multiple of 1 << GASM_RULER_SHIFT
-#define GASM_RULER_MASK ((1u << GASM_RULER_SHIFT) - 1u)
+// rulers = edges whose local index is a multiple of 1 << rshift (a launch parameter: 1 for batches of many segments —
+// every CU has its own segment, LDS time per segment is what counts — 2 for a few segments, where the LDS kernel's
+// rounds are the longest latency of the whole build and the longer walks of the other two kernels are spread over the chip)
 __global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, const u64* __restrict__ link,
-                                                         u32* __restrict__ rtab) {
+                                                         u32* __restrict__ rtab, u32 rshift) {
+    const u32 rmask = (1u << rshift) - 1u;
     u32 seg, chunk;
     if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
     const u32 r = chunk * GASM_WG + threadIdx.x;      // ruler ordinal inside the segment
-    const u32 i = lo + (r << GASM_RULER_SHIFT);
+    const u32 i = lo + (r << rshift);
     if (i >= hi) return;
     u32 cur = i, acc = 0, e = GASM_RANK_NONE;
-    for (int step = 0; step < 512; ++step) {          // the walk ends at the first even edge: 2 steps on average
+    for (int step = 0; step < 4096; ++step) {         // the walk ends at the first ruler: 2^rshift steps on average
         const u64 l = link[cur];
         const u32 a = (u32)(l >> 32);
         if (a == GASM_NONE32) break;
         acc += (u32)l & 0x7FFFFFFFu;
         const u32 al = a - lo;
-        if ((l & GASM_LINK_DONE) || !(al & GASM_RULER_MASK)) { e = (al << 16) | acc; break; }
+        if ((l & GASM_LINK_DONE) || !(al & rmask)) { e = (al << 16) | acc; break; }
         cur = a;
     }
-    rtab[(lo >> GASM_RULER_SHIFT) + seg + r] = e;     // segment s owns entries [(lo >> shift) + s, ...): room for the ragged ends
+    rtab[(lo >> rshift) + seg + r] = e;     // segment s owns entries [(lo >> shift) + s, ...): room for the ragged ends
 }
 
-__global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __restrict__ rtab, u64* __restrict__ link, int max_rounds) {
+__global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __restrict__ rtab, u64* __restrict__ link, int max_rounds,
+                                                   u32 rshift) {
+    const u32 rmask = (1u << rshift) - 1u;
     extern __shared__ u32 s_e[];
     __shared__ u32 s_active;
     const u32 seg = blockIdx.x;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 nr = (hi - lo + GASM_RULER_MASK) >> GASM_RULER_SHIFT;
-    const u32* src = rtab + (lo >> GASM_RULER_SHIFT) + seg;
+    const u32 nr = (hi - lo + rmask) >> rshift;
+    const u32* src = rtab + (lo >> rshift) + seg;
     // a thread owns entries threadIdx.x + 1024 q and keeps them in registers: a doubling step is then one LDS gather
     // (the ancestor's entry) and one LDS write (so that others see the progress) — the kernel is bound by LDS operations
     u32 mine[32];
@@ -908,7 +912,7 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
         mine[q] = r < nr ? src[r] : GASM_RANK_NONE;
         if (r < nr) s_e[r] = mine[q];
         // dead, or the ancestor is an odd head: final from the start
-        if (mine[q] == GASM_RANK_NONE || ((mine[q] >> 16) & GASM_RULER_MASK)) done |= 1u << q;
+        if (mine[q] == GASM_RANK_NONE || ((mine[q] >> 16) & rmask)) done |= 1u << q;
     }
     for (int round = 0; round < max_rounds; ++round) {
         if (threadIdx.x == 0) s_active = 0;
@@ -919,7 +923,7 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
             if (((done >> q0) & 0xFFu) == 0xFFu) continue;        // nothing open in this batch
             u32 ea[8];
 #pragma unroll
-            for (u32 u = 0; u < 8; ++u) ea[u] = ((done >> (q0 + u)) & 1u) ? 0u : s_e[mine[q0 + u] >> (16 + GASM_RULER_SHIFT)];
+            for (u32 u = 0; u < 8; ++u) ea[u] = ((done >> (q0 + u)) & 1u) ? 0u : s_e[mine[q0 + u] >> (16 + rshift)];
 #pragma unroll
             for (u32 u = 0; u < 8; ++u) {
                 const u32 q = q0 + u;
@@ -931,10 +935,10 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
                     done |= 1u << q;
                     if (!(ea[u] & 0xFFFFu)) continue;
                     ne = GASM_RANK_NONE;                                                  // ... or a cycle folded onto itself
-                } else if ((ea[u] >> 16) == (r << GASM_RULER_SHIFT)) { ne = GASM_RANK_NONE; done |= 1u << q; }   // my own cycle
+                } else if ((ea[u] >> 16) == (r << rshift)) { ne = GASM_RANK_NONE; done |= 1u << q; }   // my own cycle
                 else {
                     ne = (ea[u] & 0xFFFF0000u) | (((e & 0xFFFFu) + (ea[u] & 0xFFFFu)) & 0xFFFFu);
-                    if ((ne >> 16) & GASM_RULER_MASK) done |= 1u << q;                   // reached a head that is no ruler
+                    if ((ne >> 16) & rmask) done |= 1u << q;                   // reached a head that is no ruler
                     else any = true;
                 }
                 mine[q] = ne;
@@ -954,7 +958,7 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
         if (r >= nr) continue;
         const u32 e = mine[q];
         const bool fin = (done >> q) & 1u;
-        link[lo + (r << GASM_RULER_SHIFT)] = (fin && e != GASM_RANK_NONE) ? (((u64)(lo + (e >> 16)) << 32) | GASM_LINK_DONE | (e & 0xFFFFu)) : ~0ull;
+        link[lo + (r << rshift)] = (fin && e != GASM_RANK_NONE) ? (((u64)(lo + (e >> 16)) << 32) | GASM_LINK_DONE | (e & 0xFFFFu)) : ~0ull;
     }
 }
 

@@ -27,10 +27,11 @@ __global__ void k_add_empty_reads(PathSet ps, const u64* __restrict__ seg_empty,
 //   GASM_DEDUP_TBL=2048|4096   force the de-duplication table size        GASM_SCATTER_WGS=n   scatter workgroups per CU (8)
 //   GASM_HIST_WGS=n            histogram workgroups per CU (64)           GASM_DBG_BBITS_ADD=n extra bucket bits (tuning)
 //   GASM_DBG_PADM=m            cap the run padding at m + 1 keys          GASM_RANK_GLOBAL=1   whole-GPU list ranking only
+//   GASM_RULER_SHIFT=1..4      rulers of the LDS list ranking = every 2^n-th edge
 //   GASM_DBG_RANK_ROUNDS=n     cap the LDS ranking rounds (ablation)      GASM_DBG_DEDUP=1|2   loads only / no ordering (ablation)
 //   GASM_DBG_STAMPS=file       per-phase clock stamps of k_bucket_dedup to stderr and `file`
 struct Knobs {
-    int dedup_tbl = 0, dbg_dedup = 0, padm = -1, scatter_wgs = 8, hist_wgs = 64, rank_rounds = 18, bbits_add = 0;
+    int dedup_tbl = 0, dbg_dedup = 0, padm = -1, scatter_wgs = 8, hist_wgs = 64, rank_rounds = 18, bbits_add = 0, ruler_shift = 0;
     bool rank_global = false;
     const char* stamps = nullptr;
     Knobs() {
@@ -40,6 +41,7 @@ struct Knobs {
         if (const char* v = getenv("GASM_SCATTER_WGS")) scatter_wgs = std::max(1, atoi(v));
         if (const char* v = getenv("GASM_HIST_WGS")) hist_wgs = std::max(1, atoi(v));
         if (const char* v = getenv("GASM_DBG_BBITS_ADD")) bbits_add = std::max(0, atoi(v));
+        if (const char* v = getenv("GASM_RULER_SHIFT")) ruler_shift = std::min(4, std::max(0, atoi(v)));
         if (const char* v = getenv("GASM_DBG_RANK_ROUNDS")) rank_rounds = atoi(v);
         rank_global = getenv("GASM_RANK_GLOBAL") != nullptr;
         stamps = getenv("GASM_DBG_STAMPS");
@@ -490,15 +492,17 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     const u32 jchunks = (u32)ceil_div_u64(maxD, GASM_WG * 4);      // GASM_JUMP_ILP links per thread
     if (maxD <= 65534 && !knobs().rank_global) {
         // every second edge (the rulers) is ranked inside LDS, the others then need a step or two (kernels_build.hip)
-        const u32 max_rulers = (maxD + 1) / 2, rchunks = (u32)ceil_div_u64(max_rulers, GASM_WG);
+        // rulers: every 2nd edge when every CU has a segment of its own to rank, every 4th when segments are few
+        const u32 rshift = knobs().ruler_shift ? (u32)knobs().ruler_shift : (S >= (u32)ctx->n_cu / 4 ? 1u : 2u);
+        const u32 max_rulers = (maxD + (1u << rshift) - 1) >> rshift, rchunks = (u32)ceil_div_u64(max_rulers, GASM_WG);
         GCHK(bs.d_rtab.ensure(((size_t)D / 2 + S + 2) * 4));
         static bool rank_attr_set = false;
         if (!rank_attr_set) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
             rank_attr_set = true;
         }
-        GLAUNCH(ctx, "k_rank_rulers", k_rank_rulers, seg_grid(rchunks, S), dim3(GASM_WG), 0, gv, S, rchunks, bs.d_link.as<u64>(), bs.d_rtab.as<u32>());
-        GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)max_rulers * 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), knobs().rank_rounds);
+        GLAUNCH(ctx, "k_rank_rulers", k_rank_rulers, seg_grid(rchunks, S), dim3(GASM_WG), 0, gv, S, rchunks, bs.d_link.as<u64>(), bs.d_rtab.as<u32>(), rshift);
+        GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)max_rulers * 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), knobs().rank_rounds, rshift);
         // the odd edges: the ruler behind an edge is usually one or two steps away (a longer gap is geometrically rare)
         // (a thread stops as soon as its link is final; spans grow by a factor of jumps + 1 per launch at the very
         // least, so two launches cover any segment of this size, and the second normally returns at once)
