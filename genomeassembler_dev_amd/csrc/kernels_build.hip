@@ -177,17 +177,38 @@ __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 p
 template <class TO>
 __global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, TO* __restrict__ out, u32 n, const u32* __restrict__ tail,
                                                     u32* __restrict__ report, u32 stride, u32 count, u32 ticket) {
-    __shared__ u32 s_tmp[16];
-    TO carry = 0;
-    for (u32 base = 0; base < n; base += 1024) {
-        const u32 i = base + threadIdx.x;
-        const u32 v = i < n ? in[i] : 0u;
-        u32 tot;
-        const u32 ex = block_excl_scan<1024>(v, s_tmp, &tot);
-        if (i < n) out[i] = carry + ex;
+    __shared__ u64 s_wave[16];
+    const u32 ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u64 carry = 0;
+    // eight consecutive entries per thread and pass: one scan of the workgroup (two barriers) per 8192 entries.  The
+    // partial sums are 64-bit throughout (a pass may cover billions of k-mers).
+    for (u32 base = 0; base < n; base += 8192) {
+        const u32 i0 = base + threadIdx.x * 8;
+        u32 v[8];
+        u64 sum = 0;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) { v[q] = i0 + q < n ? in[i0 + q] : 0u; sum += v[q]; }
+        u64 inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 o = __shfl_up(inc, d, 64);
+            if ((int)ln >= d) inc += o;
+        }
+        if (ln == 63) s_wave[wv] = inc;
+        __syncthreads();
+        u64 before = 0, tot = 0;
+#pragma unroll
+        for (u32 w = 0; w < 16; ++w) { const u64 t = s_wave[w]; if (w < wv) before += t; tot += t; }
+        __syncthreads();
+        u64 ex = carry + before + inc - sum;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+            if (i0 + q < n) out[i0 + q] = (TO)ex;
+            ex += v[q];
+        }
         carry += tot;
     }
-    if (threadIdx.x == 0) out[n] = carry;
+    if (threadIdx.x == 0) out[n] = (TO)carry;
     if (report) {
         __syncthreads();          // the outputs were written by this workgroup
         for (u32 i = threadIdx.x; i <= count; i += 1024) report[i] = (u32)out[(u64)i * stride];
