@@ -86,7 +86,7 @@ extern "C" int gasm_ctx_create(int device, gasm_ctx** out) {
         return GASM_ERR_NO_DEVICE;
     }
     c->h_pin_words = 1 << 17;      // 1 MB: staging of small copies and the kernels' reports (3 words per segment)
-    if (hipHostMalloc((void**)&c->h_pin, c->h_pin_words * sizeof(u64), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&c->h_pin, c->h_pin_words * sizeof(u64), hipHostMallocCoherent) != hipSuccess) {
         (void)hipStreamDestroy(c->stream);
         delete c;
         gasm_set_error("hipHostMalloc failed");

@@ -427,6 +427,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         if ((size_t)S + 3 > ctx->h_pin_words * 2) { gasm_set_error("too many segments for the report buffer"); return GASM_ERR_CAPACITY; }
         u32* const h_rep = reinterpret_cast<u32*>(ctx->h_pin);
         const u32 ticket = next_ticket();
+        reinterpret_cast<volatile u32*>(h_rep)[S + 2] = 0;      // the polled word never holds a stale report's payload
         GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt, bs.d_flags.as<u32>(),
                 h_rep, nb, S, ticket);
         GCHK(wait_report(ctx, h_rep + S + 2, ticket));
@@ -528,6 +529,7 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     {
         u32* const h_rep = reinterpret_cast<u32*>(ctx->h_pin);
         const u32 ticket = next_ticket();
+        reinterpret_cast<volatile u32*>(h_rep)[3 * (size_t)S + 3] = 0;
         GLAUNCH(ctx, "k_seg_offsets", k_seg_offsets, dim3(1), dim3(64), 0, d_seg_ncontig, bs.d_seg_cbases.as<u64>(), S, bs.d_seg_cstart.as<u32>(),
                 bs.d_seg_bstart.as<u64>(), h_rep, ticket);
         GCHK(wait_report(ctx, h_rep + 3 * (size_t)S + 3, ticket));

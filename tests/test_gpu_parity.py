@@ -457,3 +457,104 @@ def test_full_size_segment_properties(qtable, k, rl, cov):
     for key in ("bp_score", "bp_score_norm_by_break_freqs", "kmer_breaks"):
         assert np.array_equal(sc[key], sc2[key])
     b.close()
+
+
+# ------------------------------------------------------------------------------------------------ headline shapes
+def _check_segments_vs_oracle(b, reads, seg_off, genomes, segments, k, keys, prob, contigs=None, sc=None):
+    """full oracle comparison (contigs, distinct k-mers + multiplicities, kmer_breaks exact, scores <= 1e-9) of the listed
+    segments of a built + scored batch"""
+    contigs = b.contigs() if contigs is None else contigs
+    sc = b.scores() if sc is None else sc
+    for s in segments:
+        rs = _strs(reads[int(seg_off[s]):int(seg_off[s + 1])])
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+        assert contigs[s] == ref["contigs"], f"segment {s}: contigs"
+        dk, dm = b.distinct_kmers(s)
+        assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist(), f"segment {s}: k-mer counts"
+        o = orc.calc_breakscore(contigs[s], rs, genomes[s].tobytes().decode(), 8, keys, prob, with_lev=False, with_freq=False)
+        a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+        _check_scores({kk: v[a:e] for kk, v in sc.items() if kk != "seg_contig_off"}, o, with_lev=False)
+
+
+def _check_batch_properties(b, seg_off, rl, k, n_seg):
+    """size-independent properties of every segment of a built + scored batch (numeric, no string decoding)"""
+    seg, keys_, mult, w = b.distinct()
+    sc = b.scores()
+    contigs = b.contigs()
+    for s in range(n_seg):
+        a, e = int(seg[s]), int(seg[s + 1])
+        ks = keys_[a * w:e * w].reshape(-1, w)
+        if w == 1:
+            assert (ks[1:, 0] > ks[:-1, 0]).all(), f"segment {s}: distinct k-mers not strictly sorted"
+        else:
+            gt = (ks[1:, 0] > ks[:-1, 0]) | ((ks[1:, 0] == ks[:-1, 0]) & (ks[1:, 1] > ks[:-1, 1]))
+            assert gt.all(), f"segment {s}: distinct k-mers not strictly sorted"
+        assert int(mult[a:e].astype(np.int64).sum()) == (int(seg_off[s + 1]) - int(seg_off[s])) * (rl - k + 1), f"segment {s}"
+        cs = contigs[s]
+        assert cs == sorted(set(cs)) and all(len(c) >= k for c in cs), f"segment {s}: contig order"
+        assert sum(len(c) - k + 1 for c in cs) <= e - a, f"segment {s}: chains are not edge-disjoint"
+        ca, ce = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+        assert ce - ca == len(cs)
+        assert sc["sequence_len"][ca:ce].tolist() == [len(c) for c in cs]
+        assert (sc["kmer_breaks"][ca:ce] >= 0).all()
+        assert int(sc["kmer_breaks"][ca:ce].sum()) <= int(seg_off[s + 1]) - int(seg_off[s])     # a read occurs in at most one contig
+    return contigs, sc
+
+
+@pytest.mark.parametrize("n_seg,L,rl,cov,k", [(20, 3000, 60, 25, 21), (80, 1500, 40, 30, 15), (70, 1200, 90, 20, 33)])
+def test_many_segments_against_oracle(qtable, n_seg, L, rl, cov, k):
+    """more than 8 and more than 64 segments, all against the oracle: the segment-major grids (seg_chunk), the 64-segment
+    rounds of k_seg_offsets, one workgroup per segment in k_tile_scan / k_rank_lds / k_contig_scan, and — from
+    n_cu / 4 = 64 segments on — rulers at every second edge in the LDS list ranking (the headline bench's configuration)"""
+    keys, prob = qtable
+    reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, cov, seed0=7000 + k, planted=True)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    b.build(k, genome_len_hint=L).score(8, prob)
+    contigs, sc = _check_batch_properties(b, seg_off, rl, k, n_seg)
+    _check_segments_vs_oracle(b, reads, seg_off, genomes, range(n_seg), k, keys, prob, contigs, sc)
+    b.close()
+
+
+def test_headline_shape_configs2(qtable):
+    """BASELINE configs[2] as bench.py runs it: 100 x 50 kb segments, 150 bp reads at 50x, k=31, scoring on all contigs.
+    Properties on all 100 segments; the full oracle comparison on segments either side of the 8-segment (XCD) and
+    64-segment (scan round) boundaries and at both ends."""
+    keys, prob = qtable
+    n_seg, L, rl, cov, k = 100, 50000, 150, 50, 31
+    reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, cov, seed0=1234, planted=True)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    b.build(k, genome_len_hint=L).score(8, prob)
+    assert b.total_kmers() == reads.shape[0] * (rl - k + 1)
+    contigs, sc = _check_batch_properties(b, seg_off, rl, k, n_seg)
+    _check_segments_vs_oracle(b, reads, seg_off, genomes, [0, 7, 8, 63, 64, 99], k, keys, prob, contigs, sc)
+    b.close()
+
+
+def test_headline_shape_configs4_per_gpu(qtable):
+    """BASELINE configs[4]'s shape per GPU with more than 8 segments: 50 kb, 250 bp reads at 100x, k=51 (128-bit keys).
+    Properties on all segments, the oracle on the first, the ninth and the last."""
+    keys, prob = qtable
+    n_seg, L, rl, cov, k = 10, 50000, 250, 100, 51
+    reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, cov, seed0=5150, planted=True)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    b.build(k, genome_len_hint=L).score(8, prob)
+    contigs, sc = _check_batch_properties(b, seg_off, rl, k, n_seg)
+    _check_segments_vs_oracle(b, reads, seg_off, genomes, [0, 8, 9], k, keys, prob, contigs, sc)
+    b.close()
+
+
+def test_alternating_batch_shapes_on_one_context(qtable):
+    """batches of 5, 1, 3, 12 and again 1 segment(s) built one after the other on the same Context: the reports the
+    kernels write into the context's pinned area change layout with the number of segments, stale words must never be
+    taken for a fresh report"""
+    keys, prob = qtable
+    ctx = ga.Context(0)
+    for rep, (n_seg, k) in enumerate([(5, 15), (1, 15), (3, 21), (12, 15), (1, 33), (5, 15)]):
+        rl = 50
+        reads, seg_off, genomes = synth.make_batch(n_seg, 1200 + 100 * rep, rl, 20, seed0=300 + 17 * rep, planted=True)
+        b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl, ctx=ctx)
+        for _ in range(2):
+            b.build(k).score(8, prob)
+            _check_segments_vs_oracle(b, reads, seg_off, genomes, range(n_seg), k, keys, prob)
+        b.close()
+    ctx.close()
