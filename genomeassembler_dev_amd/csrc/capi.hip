@@ -38,7 +38,27 @@ struct gasm_batch {
     ScoreState ss;
     bool built = false, paths_ready = false, table_set = false;
     std::vector<double> table_copy;
+    // the last gasm_batch_score, kept to queue it again behind a build that had to be repeated
+    bool scored = false;
+    int score_kmer = 0;
 };
+
+// Read the report of the queued build (repeating the build if it failed, and then the scoring queued behind it).
+static int batch_finish(gasm_batch* b) {
+    bool rebuilt = false;
+    GCHK(pipeline_build_finish(b->ctx, b->rd, b->bs, &rebuilt));
+    if (rebuilt) {
+        b->paths_ready = false;
+        if (b->scored) {
+            GCHK(pipeline_contig_paths(b->ctx, b->rd, b->bs, b->dp));
+            b->paths_ready = true;
+            GCHK(pipeline_build_finish(b->ctx, b->rd, b->bs, nullptr));
+            pipeline_contig_paths_host(b->rd, b->bs, b->dp);
+            GCHK(pipeline_score_launch(b->ctx, b->rd, b->dp, b->score_kmer, b->tb, false, false, b->ss, &b->bs));
+        }
+    }
+    return GASM_OK;
+}
 
 #define API_GUARD_BEGIN try {
 #define API_GUARD_END                                                          \
@@ -290,7 +310,7 @@ void gasm_batch_free(gasm_batch* b) {
 int gasm_batch_build(gasm_batch* b, int k, uint64_t genome_len_hint) {
     API_GUARD_BEGIN
     if (!b) { gasm_set_error("batch is null"); return GASM_ERR_INVALID; }
-    b->built = false; b->paths_ready = false; b->ss.valid = false; b->ss.launched = false;
+    b->built = false; b->paths_ready = false; b->ss.valid = false; b->ss.launched = false; b->scored = false;
     GCHK(pipeline_build(b->ctx, b->rd, k, genome_len_hint, b->bs));
     b->built = true;
     return GASM_OK;
@@ -306,11 +326,18 @@ int gasm_batch_score(gasm_batch* b, int kmer, const double* table) {
         b->table_copy.assign(table, table + GASM_TABLE_ROWS);
         b->table_set = true;
     }
+    // reads shorter than k (or none): the general scorer, which sizes its tables on the host — after the build's report
+    const bool through_graph = pipeline_score_uses_graph(b->rd, b->bs);
+    if (!through_graph) GCHK(batch_finish(b));
     if (!b->paths_ready) {
         GCHK(pipeline_contig_paths(b->ctx, b->rd, b->bs, b->dp));
         b->paths_ready = true;
     }
-    return pipeline_score_launch(b->ctx, b->rd, b->dp, kmer, b->tb, false, false, b->ss, &b->bs);
+    if (!through_graph) pipeline_contig_paths_host(b->rd, b->bs, b->dp);
+    GCHK(pipeline_score_launch(b->ctx, b->rd, b->dp, kmer, b->tb, false, false, b->ss, &b->bs));
+    b->scored = true;
+    b->score_kmer = kmer;
+    return GASM_OK;
     API_GUARD_END
 }
 
@@ -321,6 +348,7 @@ int gasm_batch_fetch_distinct(gasm_batch* b, const uint64_t** seg_off, const uin
     API_GUARD_BEGIN
     if (!b || !seg_off || !keys || !mult || !words) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
+    GCHK(batch_finish(b));
     GCHK(pipeline_fetch_distinct(b->ctx, b->rd, b->bs));
     *seg_off = b->bs.h_seg_doff.data();
     *keys = b->bs.h_dk_key.data();
@@ -334,6 +362,7 @@ int gasm_batch_fetch_contigs(gasm_batch* b, const uint64_t** seg_contig_off, con
     API_GUARD_BEGIN
     if (!b || !seg_contig_off || !off || !data) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
+    GCHK(batch_finish(b));
     GCHK(pipeline_fetch_contigs(b->ctx, b->rd, b->bs));
     *seg_contig_off = b->bs.h_seg_coff.data();
     *off = b->bs.h_c_off.data();
@@ -346,6 +375,7 @@ int gasm_batch_fetch_scores(gasm_batch* b, const double** bp_score, const double
                             const int32_t** kmer_breaks, const int32_t** sequence_len) {
     API_GUARD_BEGIN
     if (!b || !bp_score || !norm_by_break_freqs || !norm_by_len || !kmer_breaks || !sequence_len) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
+    GCHK(batch_finish(b));
     GCHK(pipeline_score_fetch(b->ctx, b->ss));
     *bp_score = b->ss.h_bp.data();
     *norm_by_break_freqs = b->ss.h_nf.data();

@@ -90,6 +90,20 @@ __device__ __forceinline__ bool seg_chunk(u32 n_segments, u32 chunks, u32* seg, 
     return *seg < n_segments;
 }
 
+// The edges of a segment, `chunks` workgroups per segment.  The launch takes `chunks` from an estimate of the largest
+// segment (the host does not wait for the real sizes); a segment with more edges than chunks * GASM_WG is covered by
+// further rounds of the same workgroups.  f(seg, lo, hi, i) for every edge i in [lo, hi) of the workgroup's segment.
+template <class F>
+__device__ __forceinline__ void for_seg_edges(const u32* __restrict__ dstart, u32 nb, u32 n_segments, u32 chunks, F&& f) {
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
+    const u32 lo = dstart[seg * nb], hi = dstart[(seg + 1) * nb];
+    for (u32 base = chunk * GASM_WG; base < hi - lo; base += chunks * GASM_WG) {
+        const u32 i = lo + base + threadIdx.x;
+        if (i < hi) f(seg, lo, hi, i);
+    }
+}
+
 template <class T>
 __device__ __forceinline__ u32 lower_bound_dev(const T* __restrict__ a, u32 lo, u32 hi, T t) {
     while (lo < hi) {

@@ -70,6 +70,7 @@ struct gasm_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int n_cu = 256;
+    bool lds_attrs_set = false;           // the > 64 KB dynamic-LDS opt-ins of this device's kernels (pipeline.hip)
     // small pinned host area for read-backs of counters/flags
     u64* h_pin = nullptr;
     size_t h_pin_words = 0;

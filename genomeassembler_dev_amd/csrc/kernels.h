@@ -67,12 +67,13 @@ struct PathSet {
 #define GASM_TBL_LIMIT 2816 // distinct keys one bucket may hold (11/16 of the table) before the host re-partitions
 
 // ---- kernels_build.hip
-__global__ void k_pack_ascii(const u8* ascii, u64 nbases, u64* words, u64 nwords, u32* err);
+__global__ void k_pack_ascii(const u8* ascii, u64 nbases_host, const u64* nbases_dev, u64* words, u32* err);
 #define GASM_TILE_WG 512     // threads of a tile workgroup (k_tile_hist, k_bucket_scatter)
 template <class K> __global__ void k_tile_hist(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 n_tiles, ushort4* tcnt);
 __global__ void k_tile_scan(ReadSet rs, int bbits, u32 padm, const ushort4* tcnt, u32* toff, u32* hist);
-template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n, const u32* tail, u32* report, u32 stride, u32 count, u32 ticket);
-__global__ void k_seg_offsets(const u32* seg_ncontig, const u64* seg_cbases, u32 S, u32* seg_cstart, u64* seg_bstart, u32* report, u32 ticket);
+template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
+__global__ void k_seg_offsets(const u32* seg_ncontig, const u64* seg_cbases, u32 S, u32* seg_cstart, u64* seg_bstart, const u32* dstart, u32 nb,
+                              const u32* flags, u32* report, u32 ticket);
 __global__ void k_copy_u64(const u64* a, u64* b, u32 n);
 template <class K>
 __global__ void k_bucket_scatter(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 padm, u32 n_tiles, const u64* bstart, const u32* toff,
@@ -89,16 +90,15 @@ template <class K>
 __global__ void k_node_flags(GraphView gv, u32 n_segments, u32 chunks, const u32* claim, u8* eflag, u64* link, u32* clen);
 __global__ void k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u32* tgt, const u8* eflag, u32* nxt, u64* link);
 __global__ void k_link_jump(GraphView gv, u32 n_segments, u32 chunks, u64* link, const u32* prev_active, u32* active, int jumps);
-__global__ void k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, const u64* link, u32* rtab, u32 rshift);
-__global__ void k_rank_lds(GraphView gv, const u32* rtab, u64* link, int max_rounds, u32 rshift);
-__global__ void k_chain_len(const u8* eflag, const u32* nxt, const u64* link, u32* clen, u32 n_edges);
+__global__ void k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, const u64* link, u32* rtab, u32 rshift, u32* flags);
+__global__ void k_rank_lds(GraphView gv, const u32* rtab, u64* link, int max_rounds, u32 rshift, u32 lds_entries, u32* flags);
+__global__ void k_chain_len(const u32* nxt, const u64* link, u32* clen, const u32* n_edges_p);
 __global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u32* e_cid, u64* e_coff, u32* seg_ncontig,
                               u64* seg_cbases);
-__global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* clen, const u32* seg_cstart,
-                               const u64* seg_bstart, u32* e_cid, u64* e_coff, u64* c_off, u32 n_segments, u32 chunks, u32 n_contigs,
-                               u64 contig_bases);
+__global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* seg_cstart, const u64* seg_bstart, u32* e_cid, u64* e_coff,
+                               u64* c_off, u32 n_segments, u32 chunks);
 template <class K>
-__global__ void k_contig_emit(GraphView gv, const u8* eflag, const u64* link, const u64* e_coff, u8* out, u32 n_segments, u32 chunks);
+__global__ void k_contig_emit(GraphView gv, const u64* link, const u64* e_coff, u8* out, u32 n_segments, u32 chunks);
 
 // ---- kernels_score.hip
 struct SeedTable {
@@ -114,9 +114,10 @@ template <class K>
 __global__ void k_score_reads_graph(ReadSet rs, GraphView gv, const u64* link, const u32* e_cid, PathSet ps, const long long* dfix,
                                     int kmer, u32 reads_per_wg, u32 chunks, u32 lds_paths, u32* cnt, unsigned long long* sum);
 __global__ void k_levenshtein(PathSet ps, u32 n_paths, const u64* twords, u32 nt, int infix, u8* carry_ws, u64 carry_stride, int32_t* out);
+__global__ void k_score_zero(u32* cnt, unsigned long long* sum, const u32* n_paths_p);
 __global__ void k_score_finish(PathSet ps, const u32* cnt, const unsigned long long* sum, const long long* dfix, const u64* seg_empty,
                                int kmer, double inv_scale, double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,
-                               int32_t* seq_len, u32 n_paths);
+                               int32_t* seq_len, const u32* n_paths_p);
 __global__ void k_path_reduce(PathSet ps, const u32* poscnt, const u32* extra, const double* dprob, int kmer,
                               double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,
                               int32_t* seq_len, u32 n_paths);

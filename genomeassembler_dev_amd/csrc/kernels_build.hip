@@ -25,36 +25,40 @@
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
 // ================================================================================================================
-// ASCII -> 2-bit.  One thread per output word (32 bases); 2 x 16-byte loads where the word is fully inside.
+// ASCII -> 2-bit.  One thread per output word (32 bases) and grid-stride round; 2 x 16-byte loads where the word is fully
+// inside.  nbases_dev (optional): the number of bases lives on the device (the contigs of a build the host has not
+// waited for).  Four zero padding words follow the last base.
 // ================================================================================================================
-__global__ void __launch_bounds__(GASM_WG) k_pack_ascii(const u8* __restrict__ ascii, u64 nbases,
-                                                        u64* __restrict__ words, u64 nwords, u32* __restrict__ err) {
-    const u64 t = (u64)blockIdx.x * GASM_WG + threadIdx.x;
-    if (t >= nwords) return;
-    const u64 b0 = t << 5;
-    u64 w = 0;
+__global__ void __launch_bounds__(GASM_WG) k_pack_ascii(const u8* __restrict__ ascii, u64 nbases_host, const u64* __restrict__ nbases_dev,
+                                                        u64* __restrict__ words, u32* __restrict__ err) {
+    const u64 nbases = nbases_dev ? *nbases_dev : nbases_host;
+    const u64 nwords = (nbases + 31) / 32 + 4;
     bool ok = true;
-    if (b0 + 32 <= nbases) {
-        const uint4* src = reinterpret_cast<const uint4*>(ascii + b0);
-        const uint4 v0 = src[0], v1 = src[1];
-        const u32 d[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    for (u64 t = (u64)blockIdx.x * GASM_WG + threadIdx.x; t < nwords; t += (u64)gridDim.x * GASM_WG) {
+        const u64 b0 = t << 5;
+        u64 w = 0;
+        if (b0 + 32 <= nbases) {
+            const uint4* src = reinterpret_cast<const uint4*>(ascii + b0);
+            const uint4 v0 = src[0], v1 = src[1];
+            const u32 d[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 8; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const u8 c = (u8)(d[i] >> (8 * j));
-                ok = ok && base_ok(c);
+                for (int j = 0; j < 4; ++j) {
+                    const u8 c = (u8)(d[i] >> (8 * j));
+                    ok = ok && base_ok(c);
+                    w = (w << 2) | base_code(c);
+                }
+            }
+        } else {
+            for (int j = 0; j < 32; ++j) {
+                u8 c = 'A';
+                if (b0 + j < nbases) { c = ascii[b0 + j]; ok = ok && base_ok(c); }
                 w = (w << 2) | base_code(c);
             }
         }
-    } else {
-        for (int j = 0; j < 32; ++j) {
-            u8 c = 'A';
-            if (b0 + j < nbases) { c = ascii[b0 + j]; ok = ok && base_ok(c); }
-            w = (w << 2) | base_code(c);
-        }
+        words[t] = w;
     }
-    words[t] = w;
     if (!ok && err) atomicOr(err, 1u);
 }
 
@@ -171,12 +175,9 @@ __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 p
     }
 }
 
-// Exclusive scan of n u32 into n+1 outputs of type TO; one workgroup of 1024 threads, running carry.  `report`
-// (optional, pinned host memory the device can write): every `stride`-th output, count + 1 of them, then the word at
-// `tail` — what the host needs after its wait, without a copy engine in between.
+// Exclusive scan of n u32 into n+1 outputs of type TO; one workgroup of 1024 threads, running carry.
 template <class TO>
-__global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, TO* __restrict__ out, u32 n, const u32* __restrict__ tail,
-                                                    u32* __restrict__ report, u32 stride, u32 count, u32 ticket) {
+__global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, TO* __restrict__ out, u32 n) {
     __shared__ u64 s_wave[16];
     const u32 ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
     u64 carry = 0;
@@ -209,28 +210,29 @@ __global__ void __launch_bounds__(1024) k_scan_excl(const u32* __restrict__ in, 
         carry += tot;
     }
     if (threadIdx.x == 0) out[n] = (TO)carry;
-    if (report) {
-        __syncthreads();          // the outputs were written by this workgroup
-        for (u32 i = threadIdx.x; i <= count; i += 1024) report[i] = (u32)out[(u64)i * stride];
-        if (threadIdx.x == 0) report[count + 1] = tail ? *tail : 0u;
-        // the ticket goes last: the host spins on it instead of sleeping in a stream wait
-        __threadfence_system();
-        __syncthreads();
-        if (threadIdx.x == 0) { __threadfence_system(); report[count + 2] = ticket; }
-    }
 }
-template __global__ void k_scan_excl<u64>(const u32*, u64*, u32, const u32*, u32*, u32, u32, u32);
-template __global__ void k_scan_excl<u32>(const u32*, u32*, u32, const u32*, u32*, u32, u32, u32);
+template __global__ void k_scan_excl<u64>(const u32*, u64*, u32);
+template __global__ void k_scan_excl<u32>(const u32*, u32*, u32);
 
-// Exclusive scans of the per-segment contig counts and bases (k_contig_scan) into the segment directories, on the
-// device and, for the host, in pinned memory: [0, S] contig starts, then [S + 1, 2S + 1] base starts as (lo, hi) pairs.
+// Exclusive scans of the per-segment contig counts and bases (k_contig_scan) into the segment directories — and the
+// build's REPORT: the last kernel of a build writes everything the host needs afterwards into the batch's pinned report
+// area in one go, the ticket last.  Nothing before this point makes the host wait: the build is queued in full with
+// sizes taken from upper bounds, and the host reads the report when somebody asks for results (pipeline_build_finish).
+//   report[0 .. S]            first distinct k-mer of every segment (+ the total)
+//   report[S+1 .. 2S+1]       first contig of every segment (+ the total)
+//   report[2S+2 .. 4S+3]      first contig base of every segment (+ the total), (lo, hi) pairs
+//   report[4S+4]              flags[0]: a bucket overflowed its table        report[4S+5]  flags[1]: list ranking gave up
+//   report[4S+6]              ticket
 __global__ void __launch_bounds__(64) k_seg_offsets(const u32* __restrict__ seg_ncontig, const u64* __restrict__ seg_cbases, u32 S,
-                                                    u32* __restrict__ seg_cstart, u64* __restrict__ seg_bstart, u32* __restrict__ report,
-                                                    u32 ticket) {
+                                                    u32* __restrict__ seg_cstart, u64* __restrict__ seg_bstart,
+                                                    const u32* __restrict__ dstart, u32 nb, const u32* __restrict__ flags,
+                                                    u32* __restrict__ report, u32 ticket) {
     // one wave, 64 segments at a time (a batch rarely has more than a few hundred segments)
     const u32 ln = threadIdx.x;
     u32 ccarry = 0;
     u64 bcarry = 0;
+    u32* const rc = report + S + 1;
+    u32* const rb = report + 2 * S + 2;
     for (u32 base = 0; base < S; base += 64) {
         const u32 i = base + ln;
         const u32 c = i < S ? seg_ncontig[i] : 0u;
@@ -246,19 +248,23 @@ __global__ void __launch_bounds__(64) k_seg_offsets(const u32* __restrict__ seg_
             const u32 cs = ccarry + cinc - c;
             const u64 bs = bcarry + binc - b;
             seg_cstart[i] = cs; seg_bstart[i] = bs;
-            report[i] = cs;
-            report[S + 1 + 2 * i] = (u32)bs; report[S + 2 + 2 * i] = (u32)(bs >> 32);
+            rc[i] = cs;
+            rb[2 * i] = (u32)bs; rb[2 * i + 1] = (u32)(bs >> 32);
+            report[i] = dstart[(u64)i * nb];
         }
         ccarry += wave_last(cinc);
         bcarry += __shfl(binc, 63, 64);
     }
     if (ln == 0) {
         seg_cstart[S] = ccarry; seg_bstart[S] = bcarry;
-        report[S] = ccarry;
-        report[S + 1 + 2 * S] = (u32)bcarry; report[S + 2 + 2 * S] = (u32)(bcarry >> 32);
+        rc[S] = ccarry;
+        rb[2 * S] = (u32)bcarry; rb[2 * S + 1] = (u32)(bcarry >> 32);
+        report[S] = dstart[(u64)S * nb];
+        report[4 * S + 4] = flags[0];
+        report[4 * S + 5] = flags[1];
     }
     __threadfence_system();                    // (one wave: every lane's report words are out before lane 0's ticket)
-    if (ln == 0) report[3 * S + 3] = ticket;
+    if (ln == 0) report[4 * S + 6] = ticket;
 }
 
 // ================================================================================================================
@@ -752,55 +758,44 @@ template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_edge_target(GraphView gv, u32 n_segments, u32 chunks, u32* __restrict__ tgt,
                                                          u32* __restrict__ claim) {
     const K* dk = reinterpret_cast<const K*>(gv.dk_key);
-    u32 seg, chunk;
-    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
-    const u32 nb = 1u << gv.bbits;
-    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 i = lo + chunk * GASM_WG + threadIdx.x;
-    if (i >= hi) return;
-    const K v = klowbits(dk[i], 2 * (gv.k - 1));
-    // the run of v may continue into the next bucket only if bbits > 2(k-1), which the host never chooses
-    u32 bhi;
-    const u32 j = graph_lower_bound<K>(gv, seg, kshl(v, 2), &bhi);      // smallest k-mer with prefix v
-    const bool valid = j < bhi && keq(kshr(dk[j], 2), v);
-    tgt[i] = valid ? j : GASM_NONE32;
-    if (valid) claim[j] = i;
+    for_seg_edges(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32 seg, u32, u32, u32 i) {
+        const K v = klowbits(dk[i], 2 * (gv.k - 1));
+        // the run of v may continue into the next bucket only if bbits > 2(k-1), which the host never chooses
+        u32 bhi;
+        const u32 j = graph_lower_bound<K>(gv, seg, kshl(v, 2), &bhi);      // smallest k-mer with prefix v
+        const bool valid = j < bhi && keq(kshr(dk[j], 2), v);
+        tgt[i] = valid ? j : GASM_NONE32;
+        if (valid) claim[j] = i;
+    });
 }
 template __global__ void k_edge_target<u64>(GraphView, u32, u32, u32*, u32*);
 template __global__ void k_edge_target<K128>(GraphView, u32, u32, u32*, u32*);
 
 __global__ void __launch_bounds__(GASM_WG) k_edge_multi(GraphView gv, u32 n_segments, u32 chunks, const u32* __restrict__ tgt,
                                                         const u32* __restrict__ claim, u8* __restrict__ eflag) {
-    u32 seg, chunk;
-    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
-    const u32 nb = 1u << gv.bbits;
-    const u32 i = gv.dstart[seg * nb] + chunk * GASM_WG + threadIdx.x;
-    if (i >= gv.dstart[(seg + 1) * nb]) return;
-    const u32 j = tgt[i];
-    if (j != GASM_NONE32 && claim[j] != i) eflag[j] = 2;
+    for_seg_edges(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32, u32, u32 i) {
+        const u32 j = tgt[i];
+        if (j != GASM_NONE32 && claim[j] != i) eflag[j] = 2;
+    });
 }
 
 template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u32 n_segments, u32 chunks, const u32* __restrict__ claim,
                                                         u8* __restrict__ eflag, u64* __restrict__ link, u32* __restrict__ clen) {
     const K* dk = reinterpret_cast<const K*>(gv.dk_key);
-    u32 seg, chunk;
-    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
-    const u32 nb = 1u << gv.bbits;
-    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 i = lo + chunk * GASM_WG + threadIdx.x;
-    if (i >= hi) return;
-    const K u = kshr(dk[i], 2);
-    // out-degree of u: the run of keys sharing key>>2 is contiguous in the sorted list; r = its first edge
-    u32 r = i;
-    while (r > lo && keq(kshr(dk[r - 1], 2), u)) --r;
-    u32 e = i + 1;
-    while (e < hi && keq(kshr(dk[e], 2), u)) ++e;
-    const u32 outd = e - r;
-    const bool in_one = claim[r] != GASM_NONE32 && !(eflag[r] & 2);
-    eflag[i] = (eflag[i] & 2) | ((!in_one || outd != 1) ? 1 : 0);
-    link[i] = ~0ull;      // "no ancestor" until k_edge_next says otherwise
-    clen[i] = 0;
+    for_seg_edges(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32 lo, u32 hi, u32 i) {
+        const K u = kshr(dk[i], 2);
+        // out-degree of u: the run of keys sharing key>>2 is contiguous in the sorted list; r = its first edge
+        u32 r = i;
+        while (r > lo && keq(kshr(dk[r - 1], 2), u)) --r;
+        u32 e = i + 1;
+        while (e < hi && keq(kshr(dk[e], 2), u)) ++e;
+        const u32 outd = e - r;
+        const bool in_one = claim[r] != GASM_NONE32 && !(eflag[r] & 2);
+        eflag[i] = (eflag[i] & 2) | ((!in_one || outd != 1) ? 1 : 0);
+        link[i] = ~0ull;      // "no ancestor" until k_edge_next says otherwise
+        clen[i] = 0;
+    });
 }
 template __global__ void k_node_flags<u64>(GraphView, u32, u32, const u32*, u8*, u64*, u32*);
 template __global__ void k_node_flags<K128>(GraphView, u32, u32, const u32*, u8*, u64*, u32*);
@@ -811,17 +806,14 @@ template __global__ void k_node_flags<K128>(GraphView, u32, u32, const u32*, u8*
 // (nxt may be the array claim lived in: claim is dead by now.)
 __global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u32* __restrict__ tgt,
                                                        const u8* __restrict__ eflag, u32* __restrict__ nxt, u64* __restrict__ link) {
-    u32 seg, chunk;
-    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
-    const u32 nb = 1u << gv.bbits;
-    const u32 i = gv.dstart[seg * nb] + chunk * GASM_WG + threadIdx.x;
-    if (i >= gv.dstart[(seg + 1) * nb]) return;
-    const u32 j = tgt[i];
-    const u32 n = (j != GASM_NONE32 && !(eflag[j] & 1)) ? j : GASM_NONE32;   // the target has out-edges and is not branching
-    nxt[i] = n;
-    const u64 me_head = (eflag[i] & 1) ? GASM_LINK_DONE : 0ull;
-    if (n != GASM_NONE32) link[n] = ((u64)i << 32) | me_head | 1ull;
-    if (me_head) link[i] = ((u64)i << 32) | GASM_LINK_DONE;
+    for_seg_edges(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32, u32, u32 i) {
+        const u32 j = tgt[i];
+        const u32 n = (j != GASM_NONE32 && !(eflag[j] & 1)) ? j : GASM_NONE32;   // the target has out-edges and is not branching
+        nxt[i] = n;
+        const u64 me_head = (eflag[i] & 1) ? GASM_LINK_DONE : 0ull;
+        if (n != GASM_NONE32) link[n] = ((u64)i << 32) | me_head | 1ull;
+        if (me_head) link[i] = ((u64)i << 32) | GASM_LINK_DONE;
+    });
 }
 
 // Pointer doubling towards the head of the chain, `jumps` steps per launch.  In place and asynchronous: a link is
@@ -840,37 +832,40 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
     if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;       // a segment's links stay in one XCD's L2
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 i0 = lo + chunk * (GASM_WG * GASM_JUMP_ILP) + threadIdx.x;
-    u64 l[GASM_JUMP_ILP];
-    bool act[GASM_JUMP_ILP];
-#pragma unroll
-    for (int q = 0; q < GASM_JUMP_ILP; ++q) {
-        const u32 i = i0 + q * GASM_WG;
-        l[q] = i < hi ? link[i] : ~0ull;
-        act[q] = (u32)(l[q] >> 32) != GASM_NONE32 && !(l[q] & GASM_LINK_DONE);
-    }
-    const bool mine = act[0] || act[1] || act[2] || act[3];
-    for (int j = 0; j < jumps && (act[0] || act[1] || act[2] || act[3]); ++j) {
-        u64 la[GASM_JUMP_ILP];
-#pragma unroll
-        for (int q = 0; q < GASM_JUMP_ILP; ++q)      // may be stale: fine
-            la[q] = act[q] ? __hip_atomic_load(&link[(u32)(l[q] >> 32)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+    // (`chunks` comes from an estimate of the largest segment: further rounds cover a larger one)
+    for (u32 base = chunk * (GASM_WG * GASM_JUMP_ILP); base < hi - lo; base += chunks * (GASM_WG * GASM_JUMP_ILP)) {
+        const u32 i0 = lo + base + threadIdx.x;
+        u64 l[GASM_JUMP_ILP];
+        bool act[GASM_JUMP_ILP];
 #pragma unroll
         for (int q = 0; q < GASM_JUMP_ILP; ++q) {
-            if (!act[q]) continue;
-            if ((u32)(la[q] >> 32) == GASM_NONE32) { l[q] = ~0ull; act[q] = false; continue; }   // behind a dropped edge: dropped too
-            l[q] = (la[q] & (0xFFFFFFFF00000000ull | GASM_LINK_DONE)) | (u64)(((u32)l[q] + (u32)la[q]) & 0x7FFFFFFFu);
-            if (l[q] & GASM_LINK_DONE) act[q] = false;
+            const u32 i = i0 + q * GASM_WG;
+            l[q] = i < hi ? link[i] : ~0ull;
+            act[q] = (u32)(l[q] >> 32) != GASM_NONE32 && !(l[q] & GASM_LINK_DONE);
         }
-    }
-    if (!mine) return;
-    bool open = false;
+        const bool mine = act[0] || act[1] || act[2] || act[3];
+        for (int j = 0; j < jumps && (act[0] || act[1] || act[2] || act[3]); ++j) {
+            u64 la[GASM_JUMP_ILP];
 #pragma unroll
-    for (int q = 0; q < GASM_JUMP_ILP; ++q) {
-        const u32 i = i0 + q * GASM_WG;
-        if (i < hi) { link[i] = l[q]; open = open || ((u32)(l[q] >> 32) != GASM_NONE32 && !(l[q] & GASM_LINK_DONE)); }
+            for (int q = 0; q < GASM_JUMP_ILP; ++q)      // may be stale: fine
+                la[q] = act[q] ? __hip_atomic_load(&link[(u32)(l[q] >> 32)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+#pragma unroll
+            for (int q = 0; q < GASM_JUMP_ILP; ++q) {
+                if (!act[q]) continue;
+                if ((u32)(la[q] >> 32) == GASM_NONE32) { l[q] = ~0ull; act[q] = false; continue; }   // behind a dropped edge: dropped too
+                l[q] = (la[q] & (0xFFFFFFFF00000000ull | GASM_LINK_DONE)) | (u64)(((u32)l[q] + (u32)la[q]) & 0x7FFFFFFFu);
+                if (l[q] & GASM_LINK_DONE) act[q] = false;
+            }
+        }
+        if (!mine) continue;
+        bool open = false;
+#pragma unroll
+        for (int q = 0; q < GASM_JUMP_ILP; ++q) {
+            const u32 i = i0 + q * GASM_WG;
+            if (i < hi) { link[i] = l[q]; open = open || ((u32)(l[q] >> 32) != GASM_NONE32 && !(l[q] & GASM_LINK_DONE)); }
+        }
+        if (open) *active = 1u;
     }
-    if (open) *active = 1u;
 }
 
 // ----------------------------------------------------------------------------------------------------------------
@@ -891,30 +886,36 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
 // every CU has its own segment, LDS time per segment is what counts — 2 for a few segments, where the LDS kernel's
 // rounds are the longest latency of the whole build and the longer walks of the other two kernels are spread over the chip)
 __global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, const u64* __restrict__ link,
-                                                         u32* __restrict__ rtab, u32 rshift) {
+                                                         u32* __restrict__ rtab, u32 rshift, u32* __restrict__ flags) {
     const u32 rmask = (1u << rshift) - 1u;
     u32 seg, chunk;
     if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 r = chunk * GASM_WG + threadIdx.x;      // ruler ordinal inside the segment
-    const u32 i = lo + (r << rshift);
-    if (i >= hi) return;
-    u32 cur = i, acc = 0, e = GASM_RANK_NONE;
-    for (int step = 0; step < 4096; ++step) {         // the walk ends at the first ruler: 2^rshift steps on average
-        const u64 l = link[cur];
-        const u32 a = (u32)(l >> 32);
-        if (a == GASM_NONE32) break;
-        acc += (u32)l & 0x7FFFFFFFu;
-        const u32 al = a - lo;
-        if ((l & GASM_LINK_DONE) || !(al & rmask)) { e = (al << 16) | acc; break; }
-        cur = a;
+    const u32 nr = (hi - lo + rmask) >> rshift;
+    for (u32 r = chunk * GASM_WG + threadIdx.x; r < nr; r += chunks * GASM_WG) {      // ruler ordinal inside the segment
+        const u32 i = lo + (r << rshift);
+        u32 cur = i, acc = 0, e = GASM_RANK_NONE;
+        int step = 0;
+        for (; step < 4096; ++step) {                     // the walk ends at the first ruler: 2^rshift steps on average
+            const u64 l = link[cur];
+            const u32 a = (u32)(l >> 32);
+            if (a == GASM_NONE32) break;
+            acc += (u32)l & 0x7FFFFFFFu;
+            const u32 al = a - lo;
+            if ((l & GASM_LINK_DONE) || !(al & rmask)) { e = (al << 16) | acc; break; }
+            if (a == i) break;                            // back at the start: an isolated cycle without a ruler, no contig
+            cur = a;
+        }
+        // 4096 edges in a row without a ruler: the host repeats the ranking with whole-GPU pointer doubling instead of
+        // handing out a contig that silently lost edges
+        if (step == 4096) flags[1] = 1u;
+        rtab[(lo >> rshift) + seg + r] = e;     // segment s owns entries [(lo >> shift) + s, ...): room for the ragged ends
     }
-    rtab[(lo >> rshift) + seg + r] = e;     // segment s owns entries [(lo >> shift) + s, ...): room for the ragged ends
 }
 
 __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __restrict__ rtab, u64* __restrict__ link, int max_rounds,
-                                                   u32 rshift) {
+                                                   u32 rshift, u32 lds_entries, u32* __restrict__ flags) {
     const u32 rmask = (1u << rshift) - 1u;
     extern __shared__ u32 s_e[];
     __shared__ u32 s_active;
@@ -922,6 +923,9 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
     const u32 nr = (hi - lo + rmask) >> rshift;
+    // the launch sized the LDS list from an estimate: a segment that does not fit (or has more than 65534 edges, the
+    // range of the packed entries) is left alone and reported; the host then ranks with whole-GPU pointer doubling
+    if (nr > lds_entries || hi - lo > 65534u) { if (threadIdx.x == 0) flags[1] = 1u; return; }
     const u32* src = rtab + (lo >> rshift) + seg;
     // a thread owns entries threadIdx.x + 1024 q and keeps them in registers: a doubling step is then one LDS gather
     // (the ancestor's entry) and one LDS write (so that others see the progress) — the kernel is bound by LDS operations
@@ -983,17 +987,18 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
     }
 }
 
-// Tail edges publish their chain's length (in edges) at the head.
-__global__ void __launch_bounds__(GASM_WG) k_chain_len(const u8* __restrict__ eflag, const u32* __restrict__ nxt,
-                                                       const u64* __restrict__ link, u32* __restrict__ clen, u32 n_edges) {
-    const u32 i = blockIdx.x * GASM_WG + threadIdx.x;
-    if (i >= n_edges) return;
-    if (nxt[i] != GASM_NONE32) return;
-    const u64 l = link[i];
-    const u32 a = (u32)(l >> 32);
-    if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;  // isolated cycle member: no contig starts there
-    clen[a] = ((u32)l & 0x7FFFFFFFu) + 1;
-    (void)eflag;
+// Tail edges publish their chain's length (in edges) at the head.  (grid-stride: the number of edges is only known on
+// the device, *n_edges_p = dstart[last])
+__global__ void __launch_bounds__(GASM_WG) k_chain_len(const u32* __restrict__ nxt, const u64* __restrict__ link, u32* __restrict__ clen,
+                                                       const u32* __restrict__ n_edges_p) {
+    const u32 n_edges = *n_edges_p;
+    for (u32 i = blockIdx.x * GASM_WG + threadIdx.x; i < n_edges; i += gridDim.x * GASM_WG) {
+        if (nxt[i] != GASM_NONE32) continue;
+        const u64 l = link[i];
+        const u32 a = (u32)(l >> 32);
+        if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) continue;  // isolated cycle member: no contig starts there
+        clen[a] = ((u32)l & 0x7FFFFFFFu) + 1;
+    }
 }
 
 // Per segment: rank of every head among the segment's heads and the base offset of its contig inside the segment
@@ -1061,47 +1066,39 @@ __global__ void __launch_bounds__(1024) k_contig_scan(GraphView gv, const u8* __
 }
 
 // Heads: make contig ids and offsets global; record offset and length per contig.
-__global__ void __launch_bounds__(GASM_WG) k_contig_place(GraphView gv, const u8* __restrict__ eflag, const u32* __restrict__ clen,
+__global__ void __launch_bounds__(GASM_WG) k_contig_place(GraphView gv, const u8* __restrict__ eflag,
                                                           const u32* __restrict__ seg_cstart, const u64* __restrict__ seg_bstart,
                                                           u32* __restrict__ e_cid, u64* __restrict__ e_coff,
-                                                          u64* __restrict__ c_off, u32 n_segments, u32 chunks, u32 n_contigs,
-                                                          u64 contig_bases) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) c_off[n_contigs] = contig_bases;      // end of the last contig
-    u32 seg, chunk;
-    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
-    const u32 nb = 1u << gv.bbits;
-    const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
-    const u32 i = lo + chunk * GASM_WG + threadIdx.x;
-    if (i >= hi || !(eflag[i] & 1)) return;
-    const u32 cid = seg_cstart[seg] + e_cid[i];
-    const u64 off = seg_bstart[seg] + e_coff[i];
-    e_cid[i] = cid;
-    e_coff[i] = off;
-    c_off[cid] = off;
-    (void)clen;
+                                                          u64* __restrict__ c_off, u32 n_segments, u32 chunks) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) c_off[seg_cstart[n_segments]] = seg_bstart[n_segments];      // end of the last contig
+    for_seg_edges(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32 seg, u32, u32, u32 i) {
+        if (!(eflag[i] & 1)) return;
+        const u32 cid = seg_cstart[seg] + e_cid[i];
+        const u64 off = seg_bstart[seg] + e_coff[i];
+        e_cid[i] = cid;
+        e_coff[i] = off;
+        c_off[cid] = off;
+    });
 }
 
 // Every edge on a chain writes its last base at head offset + (k-1) + distance; the head also writes its node.
 template <class K>
-__global__ void __launch_bounds__(GASM_WG) k_contig_emit(GraphView gv, const u8* __restrict__ eflag, const u64* __restrict__ link,
+__global__ void __launch_bounds__(GASM_WG) k_contig_emit(GraphView gv, const u64* __restrict__ link,
                                                          const u64* __restrict__ e_coff, u8* __restrict__ out, u32 n_segments,
                                                          u32 chunks) {
-    u32 seg, chunk;
-    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;       // the byte scatter into a segment's contigs merges in one L2
-    const u32 nb = 1u << gv.bbits;
-    const u32 i = gv.dstart[seg * nb] + chunk * GASM_WG + threadIdx.x;
-    if (i >= gv.dstart[(seg + 1) * nb]) return;
-    const u64 l = link[i];
-    const u32 a = (u32)(l >> 32);
-    if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;
-    (void)eflag;
-    const K key = reinterpret_cast<const K*>(gv.dk_key)[i];
-    const u64 off = e_coff[a];
-    const int k = gv.k;
-    out[off + (k - 1) + ((u32)l & 0x7FFFFFFFu)] = "ACGT"[klow2(key)];
-    if (a == i) {
-        for (int j = 0; j < k - 1; ++j) out[off + j] = "ACGT"[klow2(kshr(key, 2 * (k - 1 - j)))];
-    }
+    // (segment-major: the byte scatter into a segment's contigs merges in one L2)
+    for_seg_edges(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32, u32, u32 i) {
+        const u64 l = link[i];
+        const u32 a = (u32)(l >> 32);
+        if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;
+        const K key = reinterpret_cast<const K*>(gv.dk_key)[i];
+        const u64 off = e_coff[a];
+        const int k = gv.k;
+        out[off + (k - 1) + ((u32)l & 0x7FFFFFFFu)] = "ACGT"[klow2(key)];
+        if (a == i) {
+            for (int j = 0; j < k - 1; ++j) out[off + j] = "ACGT"[klow2(kshr(key, 2 * (k - 1 - j)))];
+        }
+    });
 }
-template __global__ void k_contig_emit<u64>(GraphView, const u8*, const u64*, const u64*, u8*, u32, u32);
-template __global__ void k_contig_emit<K128>(GraphView, const u8*, const u64*, const u64*, u8*, u32, u32);
+template __global__ void k_contig_emit<u64>(GraphView, const u64*, const u64*, u8*, u32, u32);
+template __global__ void k_contig_emit<K128>(GraphView, const u64*, const u64*, u8*, u32, u32);

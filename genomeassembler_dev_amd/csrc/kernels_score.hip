@@ -212,34 +212,43 @@ template __global__ void k_score_reads_graph<u64>(ReadSet, GraphView, const u64*
 template __global__ void k_score_reads_graph<K128>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32, u32, u32*,
                                                    unsigned long long*);
 
+// The batch scorer's accumulators, cleared for the paths there are (*n_paths_p lives on the device: the contigs of a build
+// the host has not waited for; a memset would have to cover the upper bound).
+__global__ void __launch_bounds__(GASM_WG) k_score_zero(u32* __restrict__ cnt, unsigned long long* __restrict__ sum, const u32* __restrict__ n_paths_p) {
+    const u32 n = *n_paths_p;
+    for (u32 p = blockIdx.x * GASM_WG + threadIdx.x; p < n; p += gridDim.x * GASM_WG) { cnt[p] = 0; sum[p] = 0; }
+}
+
 // Fixed-point sums -> the reference's per-path numbers.  `seg_empty`: empty reads of the path's segment, each a hit at
-// position 0 of every path (std::string::find("") == 0).
+// position 0 of every path (std::string::find("") == 0).  Grid-stride over *n_paths_p paths.
 __global__ void __launch_bounds__(GASM_WG) k_score_finish(PathSet ps, const u32* __restrict__ cnt, const unsigned long long* __restrict__ sum,
                                                           const long long* __restrict__ dfix, const u64* __restrict__ seg_empty,
                                                           int kmer, double inv_scale, double* __restrict__ bp_score,
                                                           double* __restrict__ norm_freq, double* __restrict__ norm_len,
-                                                          int32_t* __restrict__ kmer_breaks, int32_t* __restrict__ seq_len, u32 n_paths) {
-    const u32 p = blockIdx.x * GASM_WG + threadIdx.x;
-    if (p >= n_paths) return;
-    const u64 pb = ps.p_off[p];
-    const u32 len = (u32)(ps.p_off[p + 1] - pb);
-    u32 tot = cnt[p];
-    long long fs = (long long)sum[p];
-    if (seg_empty) {
-        const u32 seg = upper_seg<u32>(ps.seg_path_off, ps.n_segments, p);
-        const u32 e = (u32)seg_empty[seg];
-        if (e) {
-            u32 idx;
-            tot += e;
-            if (break_window(ps.words, pb, len, 0, kmer, &idx)) fs += (long long)e * dfix[idx];
+                                                          int32_t* __restrict__ kmer_breaks, int32_t* __restrict__ seq_len,
+                                                          const u32* __restrict__ n_paths_p) {
+    const u32 n_paths = *n_paths_p;
+    for (u32 p = blockIdx.x * GASM_WG + threadIdx.x; p < n_paths; p += gridDim.x * GASM_WG) {
+        const u64 pb = ps.p_off[p];
+        const u32 len = (u32)(ps.p_off[p + 1] - pb);
+        u32 tot = cnt[p];
+        long long fs = (long long)sum[p];
+        if (seg_empty) {
+            const u32 seg = upper_seg<u32>(ps.seg_path_off, ps.n_segments, p);
+            const u32 e = (u32)seg_empty[seg];
+            if (e) {
+                u32 idx;
+                tot += e;
+                if (break_window(ps.words, pb, len, 0, kmer, &idx)) fs += (long long)e * dfix[idx];
+            }
         }
+        const double s1 = (double)fs * inv_scale;
+        bp_score[p] = s1;
+        norm_freq[p] = tot ? s1 / (double)tot : 0.0;
+        norm_len[p] = s1 / (double)(int32_t)len;
+        kmer_breaks[p] = (int32_t)tot;
+        seq_len[p] = (int32_t)len;
     }
-    const double s1 = (double)fs * inv_scale;
-    bp_score[p] = s1;
-    norm_freq[p] = tot ? s1 / (double)tot : 0.0;
-    norm_len[p] = s1 / (double)(int32_t)len;
-    kmer_breaks[p] = (int32_t)tot;
-    seq_len[p] = (int32_t)len;
 }
 
 __device__ __forceinline__ u32 wave_sum_u32(u32 v) {

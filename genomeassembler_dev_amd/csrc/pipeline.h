@@ -13,6 +13,7 @@ struct DevReads {
     std::vector<u64> h_read_off;            // ragged only
     std::vector<u64> h_seg_read_off;        // n_segments+1
     std::vector<u64> h_seg_empty;           // empty reads per segment
+    u64 upload_id = 0;                      // changes with every upload: "the same reads again?" (BuildState)
     DBuf d_words, d_read_off, d_seg_read_off;
     // tile directory cache (depends on reads per tile)
     u32 tiles_ipt = 0, tiles_orr = 0, n_tiles = 0;
@@ -48,14 +49,30 @@ struct DevPaths {
 };
 
 struct BuildState {
-    int k = 0, bbits = 0, fbits = 9, words = 1;
-    u64 n_kmers = 0;
+    // ---- plan (host-side, from the reads): key width, tile shape, partition
+    int k = 0, bbits = 0, fbits = 9, words = 1, bb_cap = 0;
+    bool small_tbl = true;                  // 2048-slot de-duplication tables (else 4096)
+    bool rank_global = false;               // list ranking by whole-GPU pointer doubling only (set after the LDS ranking gave up)
+    bool ranked_in_lds = false;
+    u32 tile_g = 1;                         // threads per read of the tile kernels
+    u64 n_kmers = 0, hint = 0, reads_id = 0;
+    std::vector<u64> h_seg_nk;              // k-mers per segment
+    // upper bounds the arrays are allocated at, and estimates the grids are sized from (the kernels loop beyond them)
+    u64 D_cap = 0, maxD_cap = 0, bases_cap = 0;
+    u32 maxD_est = 1, paths_est = 0;
+    bool have_actual = false;               // maxD_est / paths_est / the partition come from a finished build of the same reads
+    // ---- report: written by the last kernels of a build into pinned memory, read by pipeline_build_finish
+    u32* h_report = nullptr;
+    size_t h_report_words = 0;
+    u32 ticket = 0;
+    bool pending = false;                   // a build is queued and its report has not been read
+    // ---- results on the host (valid after pipeline_build_finish)
     u32 d_total = 0, n_contigs = 0;
     u64 contig_bases = 0;
-    std::vector<u32> h_dstart;              // n_segments*nb+1
+    std::vector<u32> h_dstart;              // n_segments+1: first distinct k-mer of every segment
     std::vector<u32> h_seg_cstart;          // n_segments+1
     std::vector<u64> h_seg_bstart;          // n_segments+1
-    DBuf d_keys, d_mult, d_hist, d_toff, d_tcnt, d_fdir, d_bstart, d_cursor, d_bucket_d, d_dstart, d_flags, d_rtab;
+    DBuf d_keys, d_mult, d_hist, d_toff, d_tcnt, d_fdir, d_bstart, d_bucket_d, d_dstart, d_flags, d_rtab;
     DBuf d_dk_key, d_dk_cnt, d_eflag, d_nxt, d_link, d_clen, d_ecid, d_ecoff;
     DBuf d_seg_cbases, d_seg_cstart, d_seg_bstart, d_c_off, d_contig_ascii;
     // host copies filled by fetch
@@ -83,6 +100,8 @@ struct ScoreState {
     DBuf d_tbl_off, d_seed, d_gpos, d_poscnt, d_total, d_out_f64, d_out_i32, d_freq, d_pd_off, d_pd, d_seg_empty, d_fxsum, d_first, d_first_off;
     std::vector<u64> h_toff;
     u32 n_paths = 0, n_table = 0;
+    size_t stride = 1;                      // entries per output array on the device (paths + 1, or their upper bound + 1)
+    const BuildState* graph = nullptr;      // batch scoring of a build's own contigs: the number of paths comes with its report
     bool want_freq = false, want_pd = false, launched = false;
     std::vector<double> h_bp, h_nf, h_nl, h_freq, h_pd;
     std::vector<int32_t> h_breaks, h_len;
@@ -91,15 +110,23 @@ struct ScoreState {
     void release();
 };
 
+// queues a whole build on the ctx stream and returns; pipeline_build_finish (called by every fetch) waits for its report
+// and repeats it with a larger configuration if it failed.  *rebuilt: the device arrays were produced anew (a score
+// queued behind the first attempt must be queued again).
 int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 genome_len_hint, BuildState& bs);
-int pipeline_fetch_distinct(gasm_ctx* ctx, const DevReads& rd, BuildState& bs);
-int pipeline_fetch_contigs(gasm_ctx* ctx, const DevReads& rd, BuildState& bs);
-// paths of the build as a DevPaths (packs the contig text on the device)
+int pipeline_build_finish(gasm_ctx* ctx, DevReads& rd, BuildState& bs, bool* rebuilt);
+int pipeline_fetch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs);
+int pipeline_fetch_contigs(gasm_ctx* ctx, DevReads& rd, BuildState& bs);
+// paths of the build as a DevPaths (packs the contig text on the device; works on a queued build); the host-side numbers
+// of the same paths once the build's report has been read
 int pipeline_contig_paths(gasm_ctx* ctx, const DevReads& rd, const BuildState& bs, DevPaths& dp);
+void pipeline_contig_paths_host(const DevReads& rd, const BuildState& bs, DevPaths& dp);
 // graph != nullptr: dp holds the contigs of that build (same order), so reads are matched through the edge list
 int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, const ScoreTable& tb, bool want_freq,
                           bool want_pd, ScoreState& ss, const BuildState* graph);
 int pipeline_score_fetch(gasm_ctx* ctx, ScoreState& ss);
+// batch scoring can go through the build's graph (queued without waiting for the build) when every read holds a k-mer
+bool pipeline_score_uses_graph(const DevReads& rd, const BuildState& graph);
 // Levenshtein distance of every path of `dp` against `target` (ASCII) on the GPU (k_levenshtein).  *done = false when
 // the target holds a byte outside ACGT (the packed form cannot represent it): the caller then uses the host routine.
 int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 target_len, bool infix, std::vector<int32_t>& lev, bool* done);

@@ -30,9 +30,10 @@ __global__ void k_add_empty_reads(PathSet ps, const u64* __restrict__ seg_empty,
 //   GASM_RULER_SHIFT=1..4      rulers of the LDS list ranking = every 2^n-th edge
 //   GASM_DBG_RANK_ROUNDS=n     cap the LDS ranking rounds (ablation)      GASM_DBG_DEDUP=1|2   loads only / no ordering (ablation)
 //   GASM_DBG_STAMPS=file       per-phase clock stamps of k_bucket_dedup to stderr and `file`
+//   GASM_SYNC_BUILD=1          every build waits for its own report (no queued-ahead builds)
 struct Knobs {
     int dedup_tbl = 0, dbg_dedup = 0, padm = -1, scatter_wgs = 8, hist_wgs = 64, rank_rounds = 18, bbits_add = 0, ruler_shift = 0;
-    bool rank_global = false;
+    bool rank_global = false, sync_build = false;
     const char* stamps = nullptr;
     Knobs() {
         if (const char* v = getenv("GASM_DEDUP_TBL")) dedup_tbl = atoi(v);
@@ -44,6 +45,7 @@ struct Knobs {
         if (const char* v = getenv("GASM_RULER_SHIFT")) ruler_shift = std::min(4, std::max(0, atoi(v)));
         if (const char* v = getenv("GASM_DBG_RANK_ROUNDS")) rank_rounds = atoi(v);
         rank_global = getenv("GASM_RANK_GLOBAL") != nullptr;
+        sync_build = getenv("GASM_SYNC_BUILD") != nullptr;       // wait for every build's report at once (diagnostic)
         stamps = getenv("GASM_DBG_STAMPS");
     }
 };
@@ -92,7 +94,8 @@ static int pack_ascii(gasm_ctx* ctx, const u8* d_ascii, u64 nbases, DBuf& words,
     const u64 nw = (nbases + 31) / 32;
     GCHK(words.ensure((nw + 4) * 8));     // four zero padding words: a 128-bit rolling window reads up to three words ahead
     // (the kernel also writes the padding words: positions past the last base pack as zero)
-    GLAUNCH(ctx, "k_pack_ascii", k_pack_ascii, dim3(ceil_div_u64(nw + 4, GASM_WG)), dim3(GASM_WG), 0, d_ascii, nbases, words.as<u64>(), nw + 4, d_err);
+    GLAUNCH(ctx, "k_pack_ascii", k_pack_ascii, dim3(std::min<u32>(ceil_div_u64(nw + 4, GASM_WG), (u32)ctx->n_cu * 32u)), dim3(GASM_WG), 0, d_ascii, nbases,
+            (const u64*)nullptr, words.as<u64>(), d_err);
     return GASM_OK;
 }
 
@@ -149,6 +152,8 @@ int DevReads::upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 
     if (!fixed_len) GCHK(h2d(ctx, d_read_off, h_read_off.data(), (n + 1) * 8));
     GCHK(h2d(ctx, d_seg_read_off, h_seg_read_off.data(), (S + 1) * 8));
     tiles_ipt = 0;
+    static std::atomic<u64> uploads{0};
+    upload_id = ++uploads;
     return GASM_OK;
 }
 
@@ -254,10 +259,11 @@ PathSet DevPaths::view() const {
 void DevPaths::release() { d_words.release(); d_p_off.release(); d_seg_path_off.release(); d_seg_base_off.release(); }
 
 void BuildState::release() {
-    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_toff, &d_tcnt, &d_fdir, &d_bstart, &d_cursor, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
-                    &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_seg_cbases, &d_seg_cstart,
+    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_toff, &d_tcnt, &d_fdir, &d_bstart, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
+                    &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_rtab, &d_seg_cbases, &d_seg_cstart,
                     &d_seg_bstart, &d_c_off, &d_contig_ascii})
         b->release();
+    if (h_report) { (void)hipHostFree(h_report); h_report = nullptr; h_report_words = 0; }
 }
 
 void ScoreState::release() {
@@ -265,194 +271,171 @@ void ScoreState::release() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// build
+// build.  The host queues a whole build — k-mers -> buckets -> distinct k-mers -> graph -> contigs — without waiting for
+// any size: arrays are allocated at upper bounds known from the reads (288 GB of HBM are there for this), grids come from
+// estimates with the kernels looping over what is really there, and the last kernel writes every size the host will
+// need, plus the failure flags, into the batch's pinned report.  pipeline_build_finish reads it when results are asked
+// for; a build that tripped a flag (a bucket's table overflowed, list ranking's LDS estimate was too small) is repeated
+// with the next larger configuration there.  So a step of a resident pipeline (build + score, fetch much later) never
+// stalls the stream.
 // ---------------------------------------------------------------------------------------------------------------
-int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs) {
-    if (k < 2 || k > GASM_MAX_K) { gasm_set_error("k = %d not supported (2..%d)", k, GASM_MAX_K); return GASM_ERR_INVALID; }
-    const int W = k <= 31 ? 1 : 2;            // 64-bit keys up to k = 31, 128-bit keys (K128) up to k = 63
+static int ensure_lds_attrs(gasm_ctx* ctx) {
+    if (ctx->lds_attrs_set) return GASM_OK;         // per context = per device: the attribute is a property of the device's code object
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_reads_graph<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, GASM_SCORE_PATH_CAP * 12));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_reads_graph<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, GASM_SCORE_PATH_CAP * 12));
+    ctx->lds_attrs_set = true;
+    return GASM_OK;
+}
+
+// upper bound of the distinct k-mers of the segments, given the partition: a bucket holds at most `limit` (else it overflows)
+static void distinct_caps(BuildState& bs, u32 S) {
+    const u64 limit = bs.small_tbl ? GASM_TBL_LIMIT / 2 : GASM_TBL_LIMIT;
+    const u64 per_seg = ((u64)1 << bs.bbits) * limit;
+    const u64 all = bs.k < 16 ? ((u64)1 << (2 * bs.k)) : ~(u64)0;     // 4^k different k-mers exist
+    bs.D_cap = 0; bs.maxD_cap = 0;
+    for (u32 s = 0; s < S; ++s) {
+        const u64 c = std::min(std::min(bs.h_seg_nk[s], per_seg), all);
+        bs.D_cap += c;
+        bs.maxD_cap = std::max(bs.maxD_cap, c);
+    }
+}
+
+static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs);
+
+static GraphView graph_view(const BuildState& bs) {
+    GraphView gv;
+    gv.dk_key = bs.d_dk_key.p;
+    gv.dstart = bs.d_dstart.as<u32>();
+    gv.fdir = bs.d_fdir.as<u16>();
+    gv.k = bs.k;
+    gv.bbits = bs.bbits;
+    gv.fbits = bs.fbits;
+    return gv;
+}
+
+// ---- reads -> per-(segment, bucket) distinct k-mers with multiplicities (in place in d_keys / d_mult) + dstart
+static int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
+    const int k = bs.k, W = bs.words, bbits = bs.bbits;
     const size_t KB = 8 * (size_t)W;
-    const u32 KT = W == 1 ? 16u : 8u;         // k-mers per thread and round of the tile kernels (KeyTraits<K>::KT)
-    bs.words = W;
-    HIPCHK(hipSetDevice(ctx->device));
-    const u32 S = rd.n_segments;
-    bs.fetched_distinct = bs.fetched_contigs = false;
-    bs.k = k;
-    // ---- sizes known on the host
-    u64 N = 0, maxNs = 0;
-    {
-        std::vector<u64> ns(S, 0);
-        if (rd.fixed_len) {
-            const u64 nk = rd.fixed_len >= (u32)k ? rd.fixed_len - k + 1 : 0;
-            for (u32 s = 0; s < S; ++s) ns[s] = (rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]) * nk;
-        } else {
-            u32 s = 0;
-            for (u64 r = 0; r < rd.n_reads; ++r) {
-                while (r >= rd.h_seg_read_off[s + 1]) ++s;
-                const u64 L = rd.h_read_off[r + 1] - rd.h_read_off[r];
-                if (L >= (u64)k) ns[s] += L - k + 1;
-            }
-        }
-        for (u64 v : ns) { N += v; maxNs = std::max(maxNs, v); }
-    }
-    bs.n_kmers = N;
-    const u32 nk_max = rd.max_len >= (u32)k ? rd.max_len - k + 1 : 0;
-    u32 g = next_pow2_u32((nk_max + KT - 1) / KT);     // threads per read (a power of two: divides the workgroup)
-    g = std::max(1u, std::min((u32)GASM_TILE_WG, g));
-    const u32 ipt = GASM_TILE_WG / g;
-    // offset rounds: more than one only for reads with more than g*KT k-mers; every (read group, round) is a tile
-    const u32 orr = std::max(1u, (nk_max + g * KT - 1) / (g * KT));
-    if (orr > 0xFFFFu) { gasm_set_error("reads longer than %u bases are not supported", GASM_TILE_WG * KT * 0xFFFFu); return GASM_ERR_CAPACITY; }
-    GCHK(rd.set_tiles(ctx, ipt, orr));
-    // bucket bits: aim at <= ~900 distinct k-mers per bucket (2048-slot LDS table in two-slot sets, limit 1408)
-    const int bb_cap = std::min(10, 2 * (k - 1));
-    int bbits = 0;
-    {
-        const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
-        while (bbits < bb_cap && (dest >> bbits) > 900) ++bbits;
-        // few segments: up to two more bits so that there are enough (segment, bucket) workgroups to fill the chip
-        for (int extra = 0; extra < 2 && bbits < bb_cap && ((u64)S << bbits) < 1024; ++extra) ++bbits;
-        bbits = std::min(bb_cap, bbits + knobs().bbits_add);
-    }
-    GCHK(bs.d_flags.ensure(256));      // [0] bucket overflow, [16..] the list-ranking launches' "still active" words
-    bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
-    // small (2048-slot) LDS tables when the expected number of distinct k-mers per bucket is small: more workgroups per CU
-    bool small_tbl;
-    {
-        const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
-        small_tbl = (dest >> bbits) <= 900;   // else the 4096-slot table (fewer workgroups per CU)
-        if (knobs().dedup_tbl) small_tbl = knobs().dedup_tbl == 2048;
-        if (W == 2) small_tbl = true;         // 128-bit keys: 2048-slot tables only
-    }
-    const int dbg_d = knobs().dbg_dedup;
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_attr_set = true;
-    }
-    if (N == 0) {
-        bs.bbits = 0;
-        bs.h_dstart.assign((size_t)S + 1, 0);
-        bs.h_seg_cstart.assign((size_t)S + 1, 0);
-        bs.h_seg_bstart.assign((size_t)S + 1, 0);
-        GCHK(h2d(ctx, bs.d_dstart, bs.h_dstart.data(), bs.h_dstart.size() * 4));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        return GASM_OK;
-    }
+    const u32 S = rd.n_segments, nb = 1u << bbits, nbt = S * nb;
+    const u64 N = bs.n_kmers;
     // every (tile, bucket) run is padded to a multiple of padm + 1 keys (a 128-byte line when the bucket count allows;
     // the padding of one tile must fit the flush passes k_bucket_scatter has beyond KT)
     const u32 line_keys = 128 / KB, pad_room = W == 1 ? 2 * GASM_TILE_WG : GASM_TILE_WG;
-    auto pad_mask = [&](u32 nb) {
-        u32 m = line_keys - 1;
-        if (knobs().padm >= 0) m = std::min<u32>(m, (u32)knobs().padm);
-        while (m && (u64)nb * m > pad_room) m >>= 1;
-        return m;
-    };
+    u32 padm = line_keys - 1;
+    if (knobs().padm >= 0) padm = std::min<u32>(padm, (u32)knobs().padm);
+    while (padm && (u64)nb * padm > pad_room) padm >>= 1;
     const ReadSet rs = rd.view();
+    const u32 g = bs.tile_g;
     const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().hist_wgs);
     constexpr u32 SCRATCH_KEYS = 1024 * (GASM_TILE_WG / 64) * 64 * 2;   // 16 bytes per lane and wave of 1024 workgroup slots (k_bucket_scatter)
-    u32 nbt = 0;
-    while (true) {
-        const u32 nb = 1u << bbits, padm = pad_mask(nb);
-        nbt = S * nb;
-        GCHK(bs.d_hist.ensure((size_t)nbt * 4));
-        GCHK(bs.d_toff.ensure((size_t)rd.n_tiles * nb * 4));
-        const u64 n_alloc = N + (u64)padm * rd.n_tiles * nb;
-        GCHK(bs.d_keys.ensure((n_alloc + SCRATCH_KEYS) * KB));
-        GCHK(bs.d_mult.ensure(n_alloc * 4));
-        GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 8 + 64));      // four 16-bit sub-counts per (tile, bucket)
-        GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
-        GCHK(bs.d_cursor.ensure(((size_t)nbt + 1) * 8));
-        GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
-        GCHK(bs.d_dstart.ensure(((size_t)nbt + 2) * 4));
-        HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 256, ctx->stream));
-        if (W == 1) {
-            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
-                    bs.d_tcnt.as<ushort4>());
-        } else {
-            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
-                    bs.d_tcnt.as<ushort4>());
-        }
-        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S, std::max(1u, nb / 32u)), dim3(1024), 0, rs, bbits, padm, bs.d_tcnt.as<ushort4>(),
-                bs.d_toff.as<u32>(), bs.d_hist.as<u32>());
-        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt, (const u32*)nullptr, (u32*)nullptr, 0u, 0u, 0u);
-        const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
-        // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
-        const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
-        if (W == 1) {
-            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<u64>(), n_alloc);
-        } else {
-            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
-                    bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<K128>(), n_alloc);
-        }
-        unsigned long long* d_stamps = nullptr;
-        static DBuf stamp_buf;
-        if (knobs().stamps) {   // diagnostic: per-phase cycle totals of k_bucket_dedup to stderr
-            int o1 = 0, o2 = 0, o3 = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_bucket_dedup<u64, 2048>, GASM_WG, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_bucket_dedup<u64, 4096>, GASM_WG, 0);
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, k_bucket_scatter<u64>, GASM_TILE_WG, lds);
-            fprintf(stderr, "[occupancy API] dedup<2048> %d  dedup<4096> %d  scatter %d blocks/CU\n", o1, o2, o3);
-            GCHK(stamp_buf.ensure(64 + (size_t)nbt * 24));
-            HIPCHK(hipMemsetAsync(stamp_buf.p, 0, 64 + (size_t)nbt * 24, ctx->stream));
-            d_stamps = stamp_buf.as<unsigned long long>();
-        }
-        bs.fbits = small_tbl ? 9 : 10;   // bins of the de-duplication kernel's counting sort = TBL / 4
-        GCHK(bs.d_fdir.ensure((size_t)nbt * ((1u << bs.fbits) + 1) * 2));
-        // (k_bucket_dedup writes every entry of its bucket's fine directory)
-        if (W == 2) {
-            GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<K128, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
-                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
-        } else if (small_tbl) {
-            GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
-        } else {
-            GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 4096>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
-        }
-        if (d_stamps) {
-            std::vector<unsigned long long> hv(8 + (size_t)nbt * 3);
-            HIPCHK(hipMemcpyAsync(hv.data(), d_stamps, hv.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
-            const unsigned long long* h = hv.data();
-            if (FILE* f = fopen(knobs().stamps, "wb")) { fwrite(hv.data(), 8, hv.size(), f); fclose(f); }
-            fprintf(stderr, "[dedup stamps, 100 MHz ticks per workgroup] init %.1f  first-iter %.1f  stream %.1f  barrier %.1f  order %.1f  writeback %.1f\n",
-                    (double)h[0] / nbt, (double)h[1] / nbt, (double)h[2] / nbt, (double)h[3] / nbt, (double)h[4] / nbt, (double)h[5] / nbt);
-        }
-        // the scan reports the segments' first entries and the overflow flag straight into pinned host memory: one wait,
-        // no copy engine
-        if ((size_t)S + 3 > ctx->h_pin_words * 2) { gasm_set_error("too many segments for the report buffer"); return GASM_ERR_CAPACITY; }
-        u32* const h_rep = reinterpret_cast<u32*>(ctx->h_pin);
-        const u32 ticket = next_ticket();
-        reinterpret_cast<volatile u32*>(h_rep)[S + 2] = 0;      // the polled word never holds a stale report's payload
-        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt, bs.d_flags.as<u32>(),
-                h_rep, nb, S, ticket);
-        GCHK(wait_report(ctx, h_rep + S + 2, ticket));
-        bs.h_dstart.assign(h_rep, h_rep + S + 1);       // first distinct k-mer of every segment (+ the total)
-        if (!h_rep[S + 1]) break;
-        if (small_tbl && W == 1) { small_tbl = false; continue; }   // same partition, larger tables
-        if (bbits >= bb_cap) {
-            gasm_set_error("a k-mer bucket holds more than %d distinct k-mers even with %d bucket bits", GASM_TBL_LIMIT, bbits);
-            return GASM_ERR_CAPACITY;
-        }
-        bbits = std::min(bb_cap, bbits + 2);
+    GCHK(bs.d_hist.ensure((size_t)nbt * 4));
+    GCHK(bs.d_toff.ensure((size_t)rd.n_tiles * nb * 4));
+    const u64 n_alloc = N + (u64)padm * rd.n_tiles * nb;
+    GCHK(bs.d_keys.ensure((n_alloc + SCRATCH_KEYS) * KB));
+    GCHK(bs.d_mult.ensure(n_alloc * 4));
+    GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 8 + 64));      // four 16-bit sub-counts per (tile, bucket)
+    GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
+    GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
+    GCHK(bs.d_dstart.ensure(((size_t)nbt + 2) * 4));
+    HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 256, ctx->stream));
+    if (W == 1) {
+        GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
+                bs.d_tcnt.as<ushort4>());
+    } else {
+        GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
+                bs.d_tcnt.as<ushort4>());
     }
-    bs.bbits = bbits;
-    const u32 nb = 1u << bbits;
-    const u32 D = bs.h_dstart[S];
-    bs.d_total = D;
-    u32 maxD = 0;
-    for (u32 s = 0; s < S; ++s) maxD = std::max(maxD, bs.h_dstart[s + 1] - bs.h_dstart[s]);
-    bs.h_seg_cstart.assign((size_t)S + 1, 0);
-    bs.h_seg_bstart.assign((size_t)S + 1, 0);
-    if (D == 0) return GASM_OK;
-    GCHK(bs.d_dk_key.ensure((size_t)D * KB));
-    GCHK(bs.d_dk_cnt.ensure((size_t)D * 4));
+    GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S, std::max(1u, nb / 32u)), dim3(1024), 0, rs, bbits, padm, bs.d_tcnt.as<ushort4>(),
+            bs.d_toff.as<u32>(), bs.d_hist.as<u32>());
+    GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
+    const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
+    // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
+    const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
+    if (W == 1) {
+        GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
+                bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<u64>(), n_alloc);
+    } else {
+        GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
+                bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<K128>(), n_alloc);
+    }
+    unsigned long long* d_stamps = nullptr;
+    static DBuf stamp_buf;
+    if (knobs().stamps) {   // diagnostic: per-phase cycle totals of k_bucket_dedup to stderr
+        int o1 = 0, o2 = 0, o3 = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_bucket_dedup<u64, 2048>, GASM_WG, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_bucket_dedup<u64, 4096>, GASM_WG, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, k_bucket_scatter<u64>, GASM_TILE_WG, lds);
+        fprintf(stderr, "[occupancy API] dedup<2048> %d  dedup<4096> %d  scatter %d blocks/CU\n", o1, o2, o3);
+        GCHK(stamp_buf.ensure(64 + (size_t)nbt * 24));
+        HIPCHK(hipMemsetAsync(stamp_buf.p, 0, 64 + (size_t)nbt * 24, ctx->stream));
+        d_stamps = stamp_buf.as<unsigned long long>();
+    }
+    const int dbg_d = knobs().dbg_dedup;
+    bs.fbits = bs.small_tbl ? 9 : 10;   // bins of the de-duplication kernel's counting sort = TBL / 4
+    GCHK(bs.d_fdir.ensure((size_t)nbt * ((1u << bs.fbits) + 1) * 2));
+    // (k_bucket_dedup writes every entry of its bucket's fine directory)
+    if (W == 2) {
+        GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<K128, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
+                bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+    } else if (bs.small_tbl) {
+        GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+                bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+    } else {
+        GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 4096>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
+                bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+    }
+    if (d_stamps) {
+        std::vector<unsigned long long> hv(8 + (size_t)nbt * 3);
+        HIPCHK(hipMemcpyAsync(hv.data(), d_stamps, hv.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        const unsigned long long* h = hv.data();
+        if (FILE* f = fopen(knobs().stamps, "wb")) { fwrite(hv.data(), 8, hv.size(), f); fclose(f); }
+        fprintf(stderr, "[dedup stamps, 100 MHz ticks per workgroup] init %.1f  first-iter %.1f  stream %.1f  barrier %.1f  order %.1f  writeback %.1f\n",
+                (double)h[0] / nbt, (double)h[1] / nbt, (double)h[2] / nbt, (double)h[3] / nbt, (double)h[4] / nbt, (double)h[5] / nbt);
+    }
+    GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt);
+    return GASM_OK;
+}
+
+// ---- the per-edge arrays at their upper bound (the number of distinct k-mers is not known on the host)
+static int alloc_graph(BuildState& bs, u32 S) {
+    const u64 D = std::max<u64>(bs.D_cap, 1);
+    const size_t KB = 8 * (size_t)bs.words;
+    if (D >= 0xFFFFFFF0ull) { gasm_set_error("more than 2^32 distinct k-mers possible in one batch: split it"); return GASM_ERR_CAPACITY; }
+    GCHK(bs.d_dk_key.ensure(D * KB));
+    GCHK(bs.d_dk_cnt.ensure(D * 4));
     GCHK(bs.d_eflag.ensure(D));
-    GCHK(bs.d_nxt.ensure((size_t)D * 4));
+    GCHK(bs.d_nxt.ensure(D * 4));
+    GCHK(bs.d_link.ensure(D * 8));
+    GCHK(bs.d_clen.ensure(D * 4));
+    GCHK(bs.d_ecid.ensure(D * 4));
+    GCHK(bs.d_ecoff.ensure(D * 8));
+    GCHK(bs.d_rtab.ensure((D / 2 + S + 2) * 4));
+    GCHK(bs.d_seg_cbases.ensure((size_t)S * 8 + (size_t)S * 4));   // u64 bases[S] then u32 counts[S]
+    GCHK(bs.d_seg_cstart.ensure(((size_t)S + 1) * 4));
+    GCHK(bs.d_seg_bstart.ensure(((size_t)S + 1) * 8));
+    // contigs: at most one per edge, k-1 bases of the first node + one base per edge
+    bs.bases_cap = D * (u64)bs.k;
+    if (bs.bases_cap >= 0xFFFFFFF0ull) { gasm_set_error("contigs could exceed 2^32 bases: split the batch"); return GASM_ERR_CAPACITY; }
+    GCHK(bs.d_c_off.ensure((D + 1) * 8));
+    GCHK(bs.d_contig_ascii.ensure(bs.bases_cap + 64));
+    return GASM_OK;
+}
+
+// ---- dense arrays -> (k-1)-mer graph -> chains -> contigs + the report.  Inputs: d_keys/d_mult/d_bstart (the buckets'
+// distinct runs) and d_dstart/d_fdir.
+static int launch_graph(gasm_ctx* ctx, u32 S, BuildState& bs) {
+    const int W = bs.words, bbits = bs.bbits;
+    const u32 nb = 1u << bbits, nbt = S * nb;
+    GCHK(alloc_graph(bs, S));
+    // the ranking's failure flag and the "still active" words of the k_link_jump launches (the overflow flag [0] stays)
+    HIPCHK(hipMemsetAsync(bs.d_flags.as<u32>() + 1, 0, 252, ctx->stream));
     u32* const d_claim = bs.d_nxt.as<u32>();      // claim words of the degree kernels live in nxt until k_edge_next overwrites them
     if (W == 1) {
         GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<u64>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
@@ -461,23 +444,19 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<K128>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
                 bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<K128>(), bs.d_dk_cnt.as<u32>(), d_claim, bs.d_eflag.as<u8>());
     }
-    // ---- graph
-    GCHK(bs.d_link.ensure((size_t)D * 8));
-    GCHK(bs.d_clen.ensure((size_t)D * 4));
-    GCHK(bs.d_ecid.ensure((size_t)D * 4));
-    GCHK(bs.d_ecoff.ensure((size_t)D * 8));
-    GCHK(bs.d_seg_cbases.ensure((size_t)S * 8 + (size_t)S * 4));   // u64 bases[S] then u32 counts[S]: one read-back
-    u32* d_seg_ncontig = reinterpret_cast<u32*>(bs.d_seg_cbases.as<u64>() + S);
-    GraphView gv;
-    gv.dk_key = bs.d_dk_key.p;
-    gv.dstart = bs.d_dstart.as<u32>();
-    gv.fdir = bs.d_fdir.as<u16>();
-    gv.k = k;
-    gv.bbits = bbits;
-    gv.fbits = bs.fbits;
-    const u32 dchunks = (u32)ceil_div_u64(maxD, GASM_WG);     // workgroups per segment of the per-edge kernels
+    return launch_graph_dense(ctx, S, bs);
+}
+
+static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
+    const int W = bs.words;
+    u32* const d_claim = bs.d_nxt.as<u32>();
+    u32* const d_seg_ncontig = reinterpret_cast<u32*>(bs.d_seg_cbases.as<u64>() + S);
+    u32* const d_fl = bs.d_flags.as<u32>();
+    const GraphView gv = graph_view(bs);
+    const u32 nb = 1u << bs.bbits;
+    const u32 est = std::max<u32>(1, (u32)std::min<u64>(bs.maxD_est, bs.maxD_cap));   // grids: the kernels loop when a segment is larger
+    const u32 dchunks = (u32)ceil_div_u64(est, GASM_WG);     // workgroups per segment of the per-edge kernels
     const dim3 grid_seg = seg_grid(dchunks, S);
-    const dim3 grid_all(ceil_div_u64(D, GASM_WG));
     u32* const d_tgt = bs.d_ecid.as<u32>();        // first out-edge of every edge's target node; e_cid is written later (k_contig_scan)
     if (W == 1) GLAUNCH(ctx, "k_edge_target", k_edge_target<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim);
     else GLAUNCH(ctx, "k_edge_target", k_edge_target<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim);
@@ -486,24 +465,21 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     if (W == 1) GLAUNCH(ctx, "k_node_flags", k_node_flags<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_claim, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
     else GLAUNCH(ctx, "k_node_flags", k_node_flags<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_claim, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
     GLAUNCH(ctx, "k_edge_next", k_edge_next, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
-    int rounds = 1;
-    while ((1ull << rounds) < (u64)maxD) ++rounds;
-    rounds += 1;
-    u32* const act = bs.d_flags.as<u32>() + 16;     // "still active" words of the k_link_jump launches, zeroed at the start of the build
-    const u32 jchunks = (u32)ceil_div_u64(maxD, GASM_WG * 4);      // GASM_JUMP_ILP links per thread
-    if (maxD <= 65534 && !knobs().rank_global) {
+    u32* const act = d_fl + 16;     // "still active" words of the k_link_jump launches
+    const u32 jchunks = (u32)ceil_div_u64(est, GASM_WG * 4);      // GASM_JUMP_ILP links per thread
+    bs.ranked_in_lds = est <= 65534 && !bs.rank_global && !knobs().rank_global;
+    if (bs.ranked_in_lds) {
         // every second edge (the rulers) is ranked inside LDS, the others then need a step or two (kernels_build.hip)
         // rulers: every 2nd edge when every CU has a segment of its own to rank, every 4th when segments are few
         const u32 rshift = knobs().ruler_shift ? (u32)knobs().ruler_shift : (S >= (u32)ctx->n_cu / 4 ? 1u : 2u);
-        const u32 max_rulers = (maxD + (1u << rshift) - 1) >> rshift, rchunks = (u32)ceil_div_u64(max_rulers, GASM_WG);
-        GCHK(bs.d_rtab.ensure(((size_t)D / 2 + S + 2) * 4));
-        static bool rank_attr_set = false;
-        if (!rank_attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-            rank_attr_set = true;
-        }
-        GLAUNCH(ctx, "k_rank_rulers", k_rank_rulers, seg_grid(rchunks, S), dim3(GASM_WG), 0, gv, S, rchunks, bs.d_link.as<u64>(), bs.d_rtab.as<u32>(), rshift);
-        GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)max_rulers * 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), knobs().rank_rounds, rshift);
+        const u32 rchunks = (u32)ceil_div_u64((est + (1u << rshift) - 1) >> rshift, GASM_WG);
+        // LDS list of a segment: everything a workgroup can have while a CU only ever holds one of them, else the
+        // estimate with a quarter to spare (a segment that does not fit raises flags[1]: pipeline_build_finish)
+        u32 lds_entries = 32767;
+        if (S > (u32)ctx->n_cu) lds_entries = std::min<u32>(32767, (((est + est / 4) >> rshift) + 1024) & ~1023u);
+        GLAUNCH(ctx, "k_rank_rulers", k_rank_rulers, seg_grid(rchunks, S), dim3(GASM_WG), 0, gv, S, rchunks, bs.d_link.as<u64>(), bs.d_rtab.as<u32>(), rshift, d_fl);
+        GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)lds_entries * 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), knobs().rank_rounds, rshift,
+                lds_entries, d_fl);
         // the odd edges: the ruler behind an edge is usually one or two steps away (a longer gap is geometrically rare)
         // (a thread stops as soon as its link is final; spans grow by a factor of jumps + 1 per launch at the very
         // least, so two launches cover any segment of this size, and the second normally returns at once)
@@ -513,58 +489,186 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
     } else {
         // whole-GPU launches of `jumps` doubling steps each; a launch returns at once when its predecessor found every chain done
         // (spans grow by at least jumps + 1 = 5 per launch: log2(5) > 2.3 rounds' worth)
+        int rounds = 1;
+        while ((1ull << rounds) < bs.maxD_cap) ++rounds;
+        rounds += 1;
         const int jumps = 4, launches = (rounds * 10 + 22) / 23 + 1;
         if (launches > 40) { gasm_set_error("segment too large for the list-ranking flags"); return GASM_ERR_CAPACITY; }
         for (int r = 0; r < launches; ++r)
             GLAUNCH(ctx, "k_link_jump", k_link_jump, seg_grid(jchunks, S), dim3(GASM_WG), 0, gv, S, jchunks, bs.d_link.as<u64>(), r ? act + r - 1 : nullptr, act + r, jumps);
     }
-    GLAUNCH(ctx, "k_chain_len", k_chain_len, grid_all, dim3(GASM_WG), 0, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>(),
-            bs.d_clen.as<u32>(), D);
+    const u32 grid_all = (u32)std::min<u64>(ceil_div_u64((u64)est * S, GASM_WG), (u64)ctx->n_cu * 64);
+    GLAUNCH(ctx, "k_chain_len", k_chain_len, dim3(std::max(1u, grid_all)), dim3(GASM_WG), 0, bs.d_nxt.as<u32>(), bs.d_link.as<u64>(),
+            bs.d_clen.as<u32>(), gv.dstart + (size_t)S * nb);
     GLAUNCH(ctx, "k_contig_scan", k_contig_scan, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
             bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), d_seg_ncontig, bs.d_seg_cbases.as<u64>());
-    // segment directories of the contigs: scanned on the device, reported through pinned host memory (one wait, no copies)
-    if (3 * (size_t)S + 4 > ctx->h_pin_words * 2) { gasm_set_error("too many segments for the report buffer"); return GASM_ERR_CAPACITY; }
-    GCHK(bs.d_seg_cstart.ensure(((size_t)S + 1) * 4));
-    GCHK(bs.d_seg_bstart.ensure(((size_t)S + 1) * 8));
-    {
-        u32* const h_rep = reinterpret_cast<u32*>(ctx->h_pin);
-        const u32 ticket = next_ticket();
-        reinterpret_cast<volatile u32*>(h_rep)[3 * (size_t)S + 3] = 0;
-        GLAUNCH(ctx, "k_seg_offsets", k_seg_offsets, dim3(1), dim3(64), 0, d_seg_ncontig, bs.d_seg_cbases.as<u64>(), S, bs.d_seg_cstart.as<u32>(),
-                bs.d_seg_bstart.as<u64>(), h_rep, ticket);
-        GCHK(wait_report(ctx, h_rep + 3 * (size_t)S + 3, ticket));
-        for (u32 s = 0; s <= S; ++s) {
-            bs.h_seg_cstart[s] = h_rep[s];
-            bs.h_seg_bstart[s] = (u64)h_rep[S + 1 + 2 * s] | ((u64)h_rep[S + 2 + 2 * s] << 32);
-        }
+    // segment directories of the contigs + the report (ticket last)
+    const size_t words = 4 * (size_t)S + 8;
+    if (bs.h_report_words < words) {
+        if (bs.h_report) (void)hipHostFree(bs.h_report);
+        bs.h_report = nullptr; bs.h_report_words = 0;
+        HIPCHK(hipHostMalloc((void**)&bs.h_report, words * 4, hipHostMallocCoherent));
+        bs.h_report_words = words;
     }
-    bs.n_contigs = bs.h_seg_cstart[S];
-    bs.contig_bases = bs.h_seg_bstart[S];
-    if (bs.contig_bases >= 0xFFFFFFF0ull) { gasm_set_error("contigs exceed 2^32 bases"); return GASM_ERR_CAPACITY; }
-    GCHK(bs.d_c_off.ensure(((size_t)bs.n_contigs + 1) * 8));
-    GCHK(bs.d_contig_ascii.ensure(bs.contig_bases + 64));
-    if (bs.n_contigs) {
-        GLAUNCH(ctx, "k_contig_place", k_contig_place, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
-                bs.d_seg_cstart.as<u32>(), bs.d_seg_bstart.as<u64>(), bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_c_off.as<u64>(), S, dchunks,
-                bs.n_contigs, bs.contig_bases);
+    bs.ticket = next_ticket();
+    reinterpret_cast<volatile u32*>(bs.h_report)[4 * (size_t)S + 6] = 0;     // (the report of the previous build has been read or is void)
+    GLAUNCH(ctx, "k_seg_offsets", k_seg_offsets, dim3(1), dim3(64), 0, d_seg_ncontig, bs.d_seg_cbases.as<u64>(), S, bs.d_seg_cstart.as<u32>(),
+            bs.d_seg_bstart.as<u64>(), gv.dstart, nb, d_fl, bs.h_report, bs.ticket);
+    GLAUNCH(ctx, "k_contig_place", k_contig_place, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(),
+            bs.d_seg_cstart.as<u32>(), bs.d_seg_bstart.as<u64>(), bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_c_off.as<u64>(), S, dchunks);
+    if (W == 1) {
+        GLAUNCH(ctx, "k_contig_emit", k_contig_emit<u64>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_link.as<u64>(),
+                bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, dchunks);
     } else {
-        hipLaunchKernelGGL(k_set_u64, dim3(1), dim3(1), 0, ctx->stream, bs.d_c_off.as<u64>(), bs.contig_bases);
+        GLAUNCH(ctx, "k_contig_emit", k_contig_emit<K128>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_link.as<u64>(),
+                bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, dchunks);
     }
-    if (bs.n_contigs) {
-        if (W == 1) {
-            GLAUNCH(ctx, "k_contig_emit", k_contig_emit<u64>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
-                    bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, dchunks);
-        } else {
-            GLAUNCH(ctx, "k_contig_emit", k_contig_emit<K128>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(),
-                    bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, dchunks);
-        }
-    }
+    bs.pending = true;
     return GASM_OK;
 }
 
-int pipeline_fetch_distinct(gasm_ctx* ctx, const DevReads& rd, BuildState& bs) {
+// host-side sizes of a batch's reads for key width / tile shape / bucket bits
+static int plan_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs) {
+    if (k < 2 || k > GASM_MAX_K) { gasm_set_error("k = %d not supported (2..%d)", k, GASM_MAX_K); return GASM_ERR_INVALID; }
+    const int W = k <= 31 ? 1 : 2;            // 64-bit keys up to k = 31, 128-bit keys (K128) up to k = 63
+    const u32 KT = W == 1 ? 16u : 8u;         // k-mers per thread and round of the tile kernels (KeyTraits<K>::KT)
+    HIPCHK(hipSetDevice(ctx->device));
+    GCHK(ensure_lds_attrs(ctx));
+    const u32 S = rd.n_segments;
+    const bool same = bs.k == k && bs.words == W && bs.h_seg_nk.size() == S && bs.hint == hint && bs.reads_id == rd.upload_id;
+    bs.words = W; bs.k = k; bs.hint = hint; bs.reads_id = rd.upload_id;
+    bs.fetched_distinct = bs.fetched_contigs = false;
+    bs.pending = false;
+    // ---- sizes known on the host
+    u64 N = 0, maxNs = 0;
+    bs.h_seg_nk.assign(S, 0);
+    if (rd.fixed_len) {
+        const u64 nk = rd.fixed_len >= (u32)k ? rd.fixed_len - k + 1 : 0;
+        for (u32 s = 0; s < S; ++s) bs.h_seg_nk[s] = (rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]) * nk;
+    } else {
+        u32 s = 0;
+        for (u64 r = 0; r < rd.n_reads; ++r) {
+            while (r >= rd.h_seg_read_off[s + 1]) ++s;
+            const u64 L = rd.h_read_off[r + 1] - rd.h_read_off[r];
+            if (L >= (u64)k) bs.h_seg_nk[s] += L - k + 1;
+        }
+    }
+    for (u64 v : bs.h_seg_nk) { N += v; maxNs = std::max(maxNs, v); }
+    bs.n_kmers = N;
+    const u32 nk_max = rd.max_len >= (u32)k ? rd.max_len - k + 1 : 0;
+    u32 g = next_pow2_u32((nk_max + KT - 1) / KT);     // threads per read (a power of two: divides the workgroup)
+    g = std::max(1u, std::min((u32)GASM_TILE_WG, g));
+    bs.tile_g = g;
+    const u32 ipt = GASM_TILE_WG / g;
+    // offset rounds: more than one only for reads with more than g*KT k-mers; every (read group, round) is a tile
+    const u32 orr = std::max(1u, (nk_max + g * KT - 1) / (g * KT));
+    if (orr > 0xFFFFu) { gasm_set_error("reads longer than %u bases are not supported", GASM_TILE_WG * KT * 0xFFFFu); return GASM_ERR_CAPACITY; }
+    GCHK(rd.set_tiles(ctx, ipt, orr));
+    // bucket bits: aim at <= ~900 distinct k-mers per bucket (2048-slot LDS table in two-slot sets, limit 1408)
+    bs.bb_cap = std::min(10, 2 * (k - 1));
+    const u64 dest = hint ? hint : std::max<u64>(1, maxNs / 8);
+    if (!same || !bs.have_actual) {
+        int bbits = 0;
+        while (bbits < bs.bb_cap && (dest >> bbits) > 900) ++bbits;
+        // few segments: up to two more bits so that there are enough (segment, bucket) workgroups to fill the chip
+        for (int extra = 0; extra < 2 && bbits < bs.bb_cap && ((u64)S << bbits) < 1024; ++extra) ++bbits;
+        bbits = std::min(bs.bb_cap, bbits + knobs().bbits_add);
+        bs.bbits = bbits;
+        // small (2048-slot) LDS tables when the expected number of distinct k-mers per bucket is small: more workgroups per CU
+        bs.small_tbl = (dest >> bbits) <= 900;   // else the 4096-slot table (fewer workgroups per CU)
+        if (knobs().dedup_tbl) bs.small_tbl = knobs().dedup_tbl == 2048;
+        if (W == 2) bs.small_tbl = true;         // 128-bit keys: 2048-slot tables only
+        bs.maxD_est = (u32)std::min<u64>(dest, 0xFFFFFFF0ull);
+        bs.have_actual = false;
+        bs.rank_global = false;
+    }   // else: the same reads again — the partition that worked and the sizes the last build reported
+    GCHK(bs.d_flags.ensure(256));      // [0] bucket overflow, [1] list ranking gave up, [16..] the list-ranking launches' "still active" words
+    bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
+    return GASM_OK;
+}
+
+static void zero_results(BuildState& bs, u32 S) {
+    bs.h_dstart.assign((size_t)S + 1, 0);
+    bs.h_seg_cstart.assign((size_t)S + 1, 0);
+    bs.h_seg_bstart.assign((size_t)S + 1, 0);
+    bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
+}
+
+int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs) {
+    GCHK(plan_build(ctx, rd, k, hint, bs));
+    const u32 S = rd.n_segments;
+    zero_results(bs, S);
+    if (bs.n_kmers == 0) {
+        // nothing to do on the device; the directories the scorer borrows exist and are zero
+        bs.bbits = 0; bs.D_cap = 0; bs.maxD_cap = 0;
+        GCHK(alloc_graph(bs, S));
+        GCHK(bs.d_dstart.ensure(((size_t)S + 2) * 4));
+        HIPCHK(hipMemsetAsync(bs.d_dstart.p, 0, ((size_t)S + 2) * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(bs.d_seg_cstart.p, 0, ((size_t)S + 1) * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(bs.d_seg_bstart.p, 0, ((size_t)S + 1) * 8, ctx->stream));
+        HIPCHK(hipMemsetAsync(bs.d_c_off.p, 0, 8, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return GASM_OK;
+    }
+    distinct_caps(bs, S);
+    GCHK(launch_distinct(ctx, rd, bs));
+    GCHK(launch_graph(ctx, S, bs));
+    if (knobs().sync_build) GCHK(pipeline_build_finish(ctx, rd, bs, nullptr));
+    return GASM_OK;
+}
+
+// Read the report of a queued build; repeat the build with the next larger configuration while it reports a failure.
+int pipeline_build_finish(gasm_ctx* ctx, DevReads& rd, BuildState& bs, bool* rebuilt) {
+    if (rebuilt) *rebuilt = false;
+    if (!bs.pending) return GASM_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const u32 S = rd.n_segments;
+    for (;;) {
+        const u32* const rep = bs.h_report;
+        GCHK(wait_report(ctx, rep + 4 * (size_t)S + 6, bs.ticket));
+        bs.pending = false;
+        const bool overflow = rep[4 * (size_t)S + 4] != 0, rank_failed = rep[4 * (size_t)S + 5] != 0;
+        if (!overflow && !rank_failed) break;
+        if (rebuilt) *rebuilt = true;
+        if (overflow) {
+            if (bs.small_tbl && bs.words == 1) bs.small_tbl = false;      // same partition, larger tables
+            else {
+                if (bs.bbits >= bs.bb_cap) {
+                    gasm_set_error("a k-mer bucket holds more than %d distinct k-mers even with %d bucket bits", GASM_TBL_LIMIT, bs.bbits);
+                    return GASM_ERR_CAPACITY;
+                }
+                bs.bbits = std::min(bs.bb_cap, bs.bbits + 2);
+            }
+            distinct_caps(bs, S);
+            GCHK(launch_distinct(ctx, rd, bs));
+        } else {
+            bs.rank_global = true;        // whole-GPU pointer doubling instead of the LDS ranking
+        }
+        GCHK(launch_graph(ctx, S, bs));
+    }
+    const u32* const rep = bs.h_report;
+    bs.h_dstart.assign(rep, rep + S + 1);
+    u32 maxD = 0;
+    for (u32 s = 0; s <= S; ++s) {
+        bs.h_seg_cstart[s] = rep[S + 1 + s];
+        bs.h_seg_bstart[s] = (u64)rep[2 * S + 2 + 2 * s] | ((u64)rep[2 * S + 3 + 2 * s] << 32);
+        if (s < S) maxD = std::max(maxD, rep[s + 1] - rep[s]);
+    }
+    bs.d_total = bs.h_dstart[S];
+    bs.n_contigs = bs.h_seg_cstart[S];
+    bs.contig_bases = bs.h_seg_bstart[S];
+    // what the next build of the same reads starts from: sizes instead of estimates
+    bs.maxD_est = std::max(1u, maxD);
+    bs.paths_est = 1;
+    for (u32 s = 0; s < S; ++s) bs.paths_est = std::max(bs.paths_est, bs.h_seg_cstart[s + 1] - bs.h_seg_cstart[s]);
+    bs.have_actual = true;
+    return GASM_OK;
+}
+
+int pipeline_fetch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
+    GCHK(pipeline_build_finish(ctx, rd, bs, nullptr));
     if (bs.fetched_distinct) return GASM_OK;
-    const u32 S = rd.n_segments, nb = 1u << bs.bbits;
+    const u32 S = rd.n_segments;
     bs.h_seg_doff.resize((size_t)S + 1);
     for (u32 s = 0; s <= S; ++s) bs.h_seg_doff[s] = bs.h_dstart.empty() ? 0 : bs.h_dstart[s];
     bs.h_dk_key.resize((size_t)bs.d_total * bs.words);     // 128-bit keys come back as (hi, lo) pairs
@@ -578,7 +682,8 @@ int pipeline_fetch_distinct(gasm_ctx* ctx, const DevReads& rd, BuildState& bs) {
     return GASM_OK;
 }
 
-int pipeline_fetch_contigs(gasm_ctx* ctx, const DevReads& rd, BuildState& bs) {
+int pipeline_fetch_contigs(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
+    GCHK(pipeline_build_finish(ctx, rd, bs, nullptr));
     if (bs.fetched_contigs) return GASM_OK;
     const u32 S = rd.n_segments;
     bs.h_seg_coff.resize((size_t)S + 1);
@@ -594,29 +699,31 @@ int pipeline_fetch_contigs(gasm_ctx* ctx, const DevReads& rd, BuildState& bs) {
     return GASM_OK;
 }
 
+// The contigs of a build as paths: offsets and directories are the build's own device arrays (borrowed, no copy, no
+// host round trip); only the 2-bit packing of the contig text is new.  Works on a build the host has not waited for:
+// the number of bases is read on the device.
 int pipeline_contig_paths(gasm_ctx* ctx, const DevReads& rd, const BuildState& bs, DevPaths& dp) {
-    // the contigs of a build as paths: offsets and directories are the build's own device arrays (borrowed, no copy,
-    // no host round trip); only the 2-bit packing of the contig text is new
     const u32 S = rd.n_segments;
     dp.n_segments = S;
+    dp.n_paths = 0; dp.total_bases = 0;            // host-side numbers: pipeline_contig_paths_host, after the report
+    dp.h_p_off.clear(); dp.h_seg_path_off.clear(); dp.h_seg_base_off.clear();
+    dp.b_p_off = bs.d_c_off.as<u64>();
+    dp.b_seg_path_off = bs.d_seg_cstart.as<u32>();
+    dp.b_seg_base_off = bs.d_seg_bstart.as<u64>();
+    const u64 cap_words = (bs.bases_cap + 31) / 32 + 4;
+    GCHK(dp.d_words.ensure(cap_words * 8));
+    const u32 grid = (u32)std::min<u64>(ceil_div_u64(std::max<u64>(1, (u64)bs.maxD_est * S / 32 + 4), GASM_WG), (u64)ctx->n_cu * 16);
+    GLAUNCH(ctx, "k_pack_ascii", k_pack_ascii, dim3(std::max(1u, grid)), dim3(GASM_WG), 0, bs.d_contig_ascii.as<u8>(), (u64)0,
+            bs.d_seg_bstart.as<u64>() + S, dp.d_words.as<u64>(), (u32*)nullptr);
+    return GASM_OK;
+}
+
+void pipeline_contig_paths_host(const DevReads& rd, const BuildState& bs, DevPaths& dp) {
     dp.n_paths = bs.n_contigs;
     dp.total_bases = bs.contig_bases;
     dp.h_seg_path_off.assign(bs.h_seg_cstart.begin(), bs.h_seg_cstart.end());
     dp.h_seg_base_off.assign(bs.h_seg_bstart.begin(), bs.h_seg_bstart.end());
-    if (dp.h_seg_path_off.size() != (size_t)S + 1) { dp.h_seg_path_off.assign((size_t)S + 1, 0); dp.h_seg_base_off.assign((size_t)S + 1, 0); }
-    dp.h_p_off.clear();
-    dp.b_p_off = bs.n_contigs ? bs.d_c_off.as<u64>() : nullptr;
-    dp.b_seg_path_off = bs.d_seg_cstart.as<u32>();
-    dp.b_seg_base_off = bs.d_seg_bstart.as<u64>();
-    if (!bs.n_contigs) {
-        // nothing to borrow: empty directories of our own
-        dp.h_p_off.assign(1, 0);
-        dp.b_p_off = nullptr; dp.b_seg_path_off = nullptr; dp.b_seg_base_off = nullptr;
-        GCHK(dp.d_words.ensure(32));
-        HIPCHK(hipMemsetAsync(dp.d_words.p, 0, 32, ctx->stream));
-        return dp.upload_dirs(ctx);
-    }
-    return pack_ascii(ctx, bs.d_contig_ascii.as<u8>(), bs.contig_bases, dp.d_words, nullptr);
+    if (dp.h_seg_path_off.size() != (size_t)rd.n_segments + 1) { dp.h_seg_path_off.assign((size_t)rd.n_segments + 1, 0); dp.h_seg_base_off.assign((size_t)rd.n_segments + 1, 0); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -733,64 +840,94 @@ void ScoreTable::release() { d_prob.release(); d_row.release(); d_fix.release();
 // ---------------------------------------------------------------------------------------------------------------
 // score: pipeline_score_launch queues everything on the stream; pipeline_score_fetch copies the results back.
 // ---------------------------------------------------------------------------------------------------------------
+// Batch scoring of a build's own contigs (gasm_batch_score): queued behind the build without waiting for it.  The number
+// of paths is read on the device (graph.d_seg_cstart[S]); outputs are allocated at the build's upper bound.
+static int score_launch_graph(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, const ScoreTable& tb, ScoreState& ss, const BuildState& graph) {
+    const u32 S = rd.n_segments;
+    const size_t PC = (size_t)graph.D_cap + 1;
+    ss.stride = PC;
+    ss.graph = &graph;
+    ss.n_paths = 0;
+    const size_t fx_off = (PC * 4 + 15) & ~(size_t)15;
+    GCHK(ss.d_total.ensure(fx_off + PC * 8));
+    GCHK(ss.d_out_f64.ensure(PC * 8 * 3));
+    GCHK(ss.d_out_i32.ensure(PC * 4 * 2));
+    unsigned long long* const d_fx = reinterpret_cast<unsigned long long*>(static_cast<char*>(ss.d_total.p) + fx_off);
+    const u32* const n_paths_p = graph.d_seg_cstart.as<u32>() + S;
+    const u64 p_est = graph.have_actual ? std::max<u64>(graph.n_contigs, 1) : (u64)S * 256;
+    const u32 grid_p = (u32)std::max<u64>(1, std::min<u64>(ceil_div_u64(p_est, GASM_WG), (u64)ctx->n_cu * 8));
+    GLAUNCH(ctx, "k_score_zero", k_score_zero, dim3(grid_p), dim3(GASM_WG), 0, ss.d_total.as<u32>(), d_fx, n_paths_p);
+    const PathSet ps = dp.view();
+    // the paths are this build's contigs and every read holds a k-mer: the sorted edge list is the index, and the
+    // per-path sums are accumulated per read in fixed point (no position counters)
+    GraphView gv;
+    gv.dk_key = graph.d_dk_key.p;
+    gv.dstart = graph.d_dstart.as<u32>();
+    gv.fdir = graph.d_fdir.as<u16>();
+    gv.k = graph.k;
+    gv.bbits = graph.bbits;
+    gv.fbits = graph.fbits;
+    u64 max_reads = 0;
+    for (u32 s = 0; s < S; ++s) max_reads = std::max(max_reads, rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]);
+    GCHK(const_cast<ScoreTable&>(tb).set_fixed(ctx, max_reads));
+    const u32 reads_per_wg = 256;     // one read per thread: the match is a chain of dependent loads
+    const u32 rchunks = (u32)ceil_div_u64(max_reads, reads_per_wg);
+    // per-path accumulators kept in LDS: sized from the last build of these reads (a segment with more paths than that
+    // goes to global atomics: slower, same numbers)
+    const u32 lds_paths = std::min<u32>(std::max<u32>(graph.have_actual ? graph.paths_est : 1024u, 1u), GASM_SCORE_PATH_CAP);
+    if (graph.words == 1) {
+        GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<u64>, seg_grid(rchunks, S), dim3(GASM_WG), (size_t)lds_paths * 12, rd.view(),
+                gv, graph.d_link.as<u64>(), graph.d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, lds_paths, ss.d_total.as<u32>(),
+                d_fx);
+    } else {
+        GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<K128>, seg_grid(rchunks, S), dim3(GASM_WG), (size_t)lds_paths * 12, rd.view(),
+                gv, graph.d_link.as<u64>(), graph.d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, lds_paths, ss.d_total.as<u32>(),
+                d_fx);
+    }
+    double* o_bp = ss.d_out_f64.as<double>();
+    double* o_nf = o_bp + PC;
+    double* o_nl = o_nf + PC;
+    int32_t* o_br = ss.d_out_i32.as<int32_t>();
+    int32_t* o_ln = o_br + PC;
+    const u64* d_se = nullptr;
+    if (rd.n_empty) { GCHK(h2d(ctx, ss.d_seg_empty, rd.h_seg_empty.data(), (size_t)S * 8)); d_se = ss.d_seg_empty.as<u64>(); }
+    GLAUNCH(ctx, "k_score_finish", k_score_finish, dim3(grid_p), dim3(GASM_WG), 0, ps, ss.d_total.as<u32>(),
+            d_fx, tb.d_fix.as<long long>(), d_se, kmer, std::ldexp(1.0, -tb.fix_shift), o_bp, o_nf, o_nl, o_br, o_ln, n_paths_p);
+    ss.h_pd_off.clear();
+    ss.launched = true;
+    return GASM_OK;
+}
+
+bool pipeline_score_uses_graph(const DevReads& rd, const BuildState& graph) {
+    return graph.n_kmers > 0 && rd.n_reads > rd.n_empty && rd.min_len >= (u32)graph.k;
+}
+
 int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, const ScoreTable& tb, bool want_freq, bool want_pd,
                           ScoreState& ss, const BuildState* graph) {
     if (kmer < 0) { gasm_set_error("kmer must be >= 0"); return GASM_ERR_INVALID; }
     if (rd.n_segments != dp.n_segments) { gasm_set_error("reads and paths disagree on the number of segments"); return GASM_ERR_INVALID; }
     HIPCHK(hipSetDevice(ctx->device));
     ss.valid = false;
-    ss.n_paths = dp.n_paths;
     ss.n_table = tb.n_table;
     ss.want_freq = want_freq && tb.n_table;
     ss.want_pd = want_pd;
+    ss.graph = nullptr;
+    if (graph && !want_freq && !want_pd && pipeline_score_uses_graph(rd, *graph)) return score_launch_graph(ctx, rd, dp, kmer, tb, ss, *graph);
+    // ---- arbitrary paths (or reads that do not all hold a k-mer): host-side sizes are needed — the caller has uploaded
+    // the paths or, for a build's contigs, read the build's report (pipeline_contig_paths_host)
+    ss.n_paths = dp.n_paths;
     const u32 S = rd.n_segments, P = dp.n_paths;
     const u64 TB = dp.total_bases;
+    ss.stride = (size_t)P + 1;
     GCHK(ss.d_poscnt.ensure((TB + 1) * 4));
-    // per-path counters and, behind them, the 64-bit fixed-point sums of the graph scorer: one allocation, one memset
-    const size_t fx_off = (((size_t)P + 1) * 4 + 15) & ~(size_t)15;
-    GCHK(ss.d_total.ensure(fx_off + ((size_t)P + 1) * 8));
+    GCHK(ss.d_total.ensure(((size_t)P + 1) * 4));
     GCHK(ss.d_out_f64.ensure(((size_t)P + 1) * 8 * 3));
     GCHK(ss.d_out_i32.ensure(((size_t)P + 1) * 4 * 2));
-    const bool use_graph = graph && P && TB && rd.n_reads > rd.n_empty && rd.min_len >= (u32)graph->k && graph->d_total;
-    if (!use_graph) HIPCHK(hipMemsetAsync(ss.d_poscnt.p, 0, (TB + 1) * 4, ctx->stream));
-    HIPCHK(hipMemsetAsync(ss.d_total.p, 0, use_graph ? fx_off + ((size_t)P + 1) * 8 : ((size_t)P + 1) * 4, ctx->stream));
-    unsigned long long* const d_fx = reinterpret_cast<unsigned long long*>(static_cast<char*>(ss.d_total.p) + fx_off);
+    HIPCHK(hipMemsetAsync(ss.d_poscnt.p, 0, (TB + 1) * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(ss.d_total.p, 0, ((size_t)P + 1) * 4, ctx->stream));
     const PathSet ps = dp.view();
     const int w = (int)std::min<u32>(32, rd.min_len);
-    if (use_graph) {
-        // the paths are this build's contigs and every read holds a k-mer: the sorted edge list is the index, and the
-        // per-path sums are accumulated per read in fixed point (no position counters)
-        GraphView gv;
-        gv.dk_key = graph->d_dk_key.p;
-        gv.dstart = graph->d_dstart.as<u32>();
-        gv.fdir = graph->d_fdir.as<u16>();
-        gv.k = graph->k;
-        gv.bbits = graph->bbits;
-        gv.fbits = graph->fbits;
-        u64 max_reads = 0;
-        for (u32 s = 0; s < S; ++s) max_reads = std::max(max_reads, rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]);
-        GCHK(const_cast<ScoreTable&>(tb).set_fixed(ctx, max_reads));
-        const u32 reads_per_wg = 256;     // one read per thread: the match is a chain of dependent loads
-        const u32 rchunks = (u32)ceil_div_u64(max_reads, reads_per_wg);
-        u32 max_paths = 0;
-        for (u32 s = 0; s < S; ++s) max_paths = std::max(max_paths, dp.h_seg_path_off[s + 1] - dp.h_seg_path_off[s]);
-        const u32 lds_paths = std::min<u32>(std::max(max_paths, 1u), GASM_SCORE_PATH_CAP);   // per-path accumulators kept in LDS
-        static bool score_attr_set = false;
-        if (!score_attr_set) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_reads_graph<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, GASM_SCORE_PATH_CAP * 12));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_reads_graph<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, GASM_SCORE_PATH_CAP * 12));
-            score_attr_set = true;
-        }
-        if (graph->words == 1) {
-            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<u64>, seg_grid(rchunks, S), dim3(GASM_WG), (size_t)lds_paths * 12, rd.view(),
-                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, lds_paths, ss.d_total.as<u32>(),
-                    d_fx);
-        } else {
-            GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<K128>, seg_grid(rchunks, S), dim3(GASM_WG), (size_t)lds_paths * 12, rd.view(),
-                    gv, graph->d_link.as<u64>(), graph->d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, lds_paths, ss.d_total.as<u32>(),
-                    d_fx);
-        }
-    } else if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
+    if (P && TB && rd.n_reads > rd.n_empty && w >= 1) {
         // per-segment read tables (power of two, at least twice the reads) and the dense first-occurrence table
         std::vector<u64>& toff = ss.h_toff;
         toff.assign((size_t)S + 1, 0);
@@ -853,7 +990,7 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
             }
         }
     }
-    if (P && rd.n_empty && !use_graph) {
+    if (P && rd.n_empty) {
         GCHK(h2d(ctx, ss.d_seg_empty, rd.h_seg_empty.data(), (size_t)S * 8));
         u32 maxp = 0;
         for (u32 s = 0; s < S; ++s) maxp = std::max(maxp, dp.h_seg_path_off[s + 1] - dp.h_seg_path_off[s]);
@@ -865,13 +1002,7 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
     double* o_nl = o_nf + (P + 1);
     int32_t* o_br = ss.d_out_i32.as<int32_t>();
     int32_t* o_ln = o_br + (P + 1);
-    if (P && use_graph) {
-        const u64* d_se = nullptr;
-        if (rd.n_empty) { GCHK(h2d(ctx, ss.d_seg_empty, rd.h_seg_empty.data(), (size_t)S * 8)); d_se = ss.d_seg_empty.as<u64>(); }
-        GLAUNCH(ctx, "k_score_finish", k_score_finish, dim3(ceil_div_u64(P, GASM_WG)), dim3(GASM_WG), 0, ps, ss.d_total.as<u32>(),
-                d_fx, tb.d_fix.as<long long>(), d_se, kmer, std::ldexp(1.0, -tb.fix_shift), o_bp, o_nf, o_nl,
-                o_br, o_ln, P);
-    } else if (P) {
+    if (P) {
         GLAUNCH(ctx, "k_path_reduce", k_path_reduce, dim3(P), dim3(GASM_WG), 0, ps, ss.d_poscnt.as<u32>(),
                 ss.d_total.as<u32>(), tb.d_prob.as<double>(), kmer, o_bp, o_nf, o_nl, o_br, o_ln, P);
     }
@@ -903,12 +1034,16 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
 int pipeline_score_fetch(gasm_ctx* ctx, ScoreState& ss) {
     if (!ss.launched) { gasm_set_error("no scoring has been queued"); return GASM_ERR_STATE; }
     if (ss.valid) return GASM_OK;
+    if (ss.graph) {
+        if (ss.graph->pending) { gasm_set_error("scores fetched before the build's report was read"); return GASM_ERR_STATE; }
+        ss.n_paths = ss.graph->n_contigs;
+    }
     const u32 P = ss.n_paths;
     double* o_bp = ss.d_out_f64.as<double>();
-    double* o_nf = o_bp + (P + 1);
-    double* o_nl = o_nf + (P + 1);
+    double* o_nf = o_bp + ss.stride;
+    double* o_nl = o_nf + ss.stride;
     int32_t* o_br = ss.d_out_i32.as<int32_t>();
-    int32_t* o_ln = o_br + (P + 1);
+    int32_t* o_ln = o_br + ss.stride;
     ss.h_bp.resize(P); ss.h_nf.resize(P); ss.h_nl.resize(P); ss.h_breaks.resize(P); ss.h_len.resize(P);
     ss.h_freq.clear(); ss.h_pd.clear();
     std::vector<u32> h_fc;
