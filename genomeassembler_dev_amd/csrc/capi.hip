@@ -29,34 +29,59 @@ struct gasm_scores {
     bool has_freq = false, velvet = false;
 };
 
-struct gasm_batch {
-    gasm_ctx* ctx = nullptr;
+// A batch runs as one or more sub-batches — contiguous blocks of its segments, each with its own reads, build and
+// scoring state on its own stream (a lane of the context).  Segments are independent, so this changes nothing in the
+// results; it lets the latency-bound graph phase of one block run under the bandwidth-bound partition/de-duplication
+// phase of the next: block j's first kernel waits (stream event) until block j-1's streaming kernels are queued, and
+// with builds queued ahead of their reports the blocks of consecutive steps interleave the same way.
+struct SubBatch {
+    gasm_ctx* cx = nullptr;                 // the lane it runs on (lane 0 = the batch's context itself)
+    u32 seg0 = 0, seg1 = 0;                 // its block of the batch's segments
     DevReads rd;
     BuildState bs;
     DevPaths dp;
     ScoreTable tb;
     ScoreState ss;
-    bool built = false, paths_ready = false, table_set = false;
+    bool paths_ready = false, table_set = false;
+    hipEvent_t ev_streamed = nullptr;
+};
+
+struct gasm_batch {
+    gasm_ctx* ctx = nullptr;
+    std::vector<SubBatch> sub;
+    u32 n_segments = 0;
+    u64 n_reads = 0;
+    bool built = false;
     std::vector<double> table_copy;
+    bool table_given = false;
     // the last gasm_batch_score, kept to queue it again behind a build that had to be repeated
     bool scored = false;
     int score_kmer = 0;
+    // concatenated host results of the sub-batches (fetch)
+    std::vector<u64> h_seg_doff, h_dk_key, h_seg_coff, h_c_off;
+    std::vector<u32> h_dk_cnt;
+    std::vector<char> h_contigs;
+    std::vector<double> h_bp, h_nf, h_nl;
+    std::vector<int32_t> h_breaks, h_len;
 };
 
-// Read the report of the queued build (repeating the build if it failed, and then the scoring queued behind it).
-static int batch_finish(gasm_batch* b) {
+// Read the report of a sub-batch's queued build (repeating the build if it failed, and then the scoring queued behind it).
+static int sub_finish(gasm_batch* b, SubBatch& sb) {
     bool rebuilt = false;
-    GCHK(pipeline_build_finish(b->ctx, b->rd, b->bs, &rebuilt));
+    GCHK(pipeline_build_finish(sb.cx, sb.rd, sb.bs, &rebuilt));
     if (rebuilt) {
-        b->paths_ready = false;
+        sb.paths_ready = false;
         if (b->scored) {
-            GCHK(pipeline_contig_paths(b->ctx, b->rd, b->bs, b->dp));
-            b->paths_ready = true;
-            GCHK(pipeline_build_finish(b->ctx, b->rd, b->bs, nullptr));
-            pipeline_contig_paths_host(b->rd, b->bs, b->dp);
-            GCHK(pipeline_score_launch(b->ctx, b->rd, b->dp, b->score_kmer, b->tb, false, false, b->ss, &b->bs));
+            GCHK(pipeline_contig_paths(sb.cx, sb.rd, sb.bs, sb.dp));
+            sb.paths_ready = true;
+            pipeline_contig_paths_host(sb.rd, sb.bs, sb.dp);
+            GCHK(pipeline_score_launch(sb.cx, sb.rd, sb.dp, b->score_kmer, sb.tb, false, false, sb.ss, &sb.bs));
         }
     }
+    return GASM_OK;
+}
+static int batch_finish(gasm_batch* b) {
+    for (SubBatch& sb : b->sub) GCHK(sub_finish(b, sb));
     return GASM_OK;
 }
 
@@ -286,15 +311,59 @@ const uint64_t* gasm_scores_prob_dist_offsets(const gasm_scores* s) { return s &
 void gasm_scores_free(gasm_scores* s) { delete s; }
 
 // ------------------------------------------------------------------------------------------------------ batches
+static u32 sub_batches_for(u32 n_segments) {
+    // GASM_SUBBATCHES=n forces the number of blocks (1 = the whole batch on the context's own stream)
+    if (const char* v = getenv("GASM_SUBBATCHES")) return (u32)std::max(1, std::min(8, atoi(v)));
+    (void)n_segments;
+    return 1u;      // measured (cfg2, 2-4 blocks): 1.32-1.35 ms per step against 1.34 — the half-size streaming kernels lose what the overlap gains
+}
+
 int gasm_batch_create(gasm_ctx* ctx, const char* reads, const uint64_t* read_off, uint64_t n_reads, uint32_t fixed_len,
                       const uint64_t* seg_read_off, uint32_t n_segments, gasm_batch** out) {
     API_GUARD_BEGIN
     if (!ctx || !out) { gasm_set_error("gasm_batch_create: null argument"); return GASM_ERR_INVALID; }
     *out = nullptr;
+    if (n_segments == 0 || !seg_read_off) { gasm_set_error("need at least one segment and seg_read_off"); return GASM_ERR_INVALID; }
+    if (seg_read_off[0] != 0 || seg_read_off[n_segments] != n_reads) { gasm_set_error("seg_read_off must run from 0 to n_reads"); return GASM_ERR_INVALID; }
+    for (u32 s = 0; s < n_segments; ++s) if (seg_read_off[s] > seg_read_off[s + 1]) { gasm_set_error("seg_read_off not monotone"); return GASM_ERR_INVALID; }
     gasm_batch* b = new gasm_batch();
     b->ctx = ctx;
-    const int st = b->rd.upload(ctx, reads, read_off, n_reads, fixed_len, seg_read_off, n_segments);
+    b->n_segments = n_segments;
+    b->n_reads = n_reads;
+    const u32 nsub = std::min<u32>(sub_batches_for(n_segments), n_segments);
+    b->sub.resize(nsub);
+    // blocks of segments with about the same number of reads each
+    u32 seg = 0;
+    int st = GASM_OK;
+    for (u32 j = 0; j < nsub && st == GASM_OK; ++j) {
+        SubBatch& sb = b->sub[j];
+        sb.seg0 = seg;
+        const u64 want = n_reads * (u64)(j + 1) / nsub;
+        u32 e = seg + 1;
+        while (e < n_segments - (nsub - 1 - j) && seg_read_off[e] < want) ++e;
+        if (j + 1 == nsub) e = n_segments;
+        sb.seg1 = e;
+        seg = e;
+        sb.cx = j == 0 ? ctx : ctx->lane(j - 1);
+        if (!sb.cx) { st = GASM_ERR_HIP; break; }
+        std::vector<u64> so(sb.seg1 - sb.seg0 + 1);
+        const u64 r0 = seg_read_off[sb.seg0];
+        for (u32 i = 0; i < so.size(); ++i) so[i] = seg_read_off[sb.seg0 + i] - r0;
+        const char* rbase = reads;
+        const u64* ro = nullptr;
+        if (read_off) ro = read_off + r0;            // DevReads::upload rebases ragged offsets to ro[0]
+        else rbase = reads ? reads + r0 * (u64)fixed_len : reads;
+        st = sb.rd.upload(sb.cx, rbase, ro, so.back(), fixed_len, so.data(), (u32)so.size() - 1);
+        if (st == GASM_OK && nsub > 1 && hipEventCreateWithFlags(&sb.ev_streamed, hipEventDisableTiming) != hipSuccess) {
+            gasm_set_error("hipEventCreate failed");
+            st = GASM_ERR_HIP;
+        }
+    }
     if (st != GASM_OK) { gasm_batch_free(b); return st; }
+    for (u32 j = 0; j < nsub; ++j) {
+        b->sub[j].bs.ev_streamed = b->sub[j].ev_streamed;
+        b->sub[j].bs.ev_wait = j ? b->sub[j - 1].ev_streamed : nullptr;
+    }
     *out = b;
     return GASM_OK;
     API_GUARD_END
@@ -302,16 +371,22 @@ int gasm_batch_create(gasm_ctx* ctx, const char* reads, const uint64_t* read_off
 
 void gasm_batch_free(gasm_batch* b) {
     if (!b) return;
-    if (b->ctx) { (void)hipSetDevice(b->ctx->device); (void)hipStreamSynchronize(b->ctx->stream); }
-    b->rd.release(); b->bs.release(); b->dp.release(); b->tb.release(); b->ss.release();
+    for (SubBatch& sb : b->sub) {
+        if (sb.cx) { (void)hipSetDevice(sb.cx->device); (void)hipStreamSynchronize(sb.cx->stream); }
+        sb.rd.release(); sb.bs.release(); sb.dp.release(); sb.tb.release(); sb.ss.release();
+        if (sb.ev_streamed) (void)hipEventDestroy(sb.ev_streamed);
+    }
     delete b;
 }
 
 int gasm_batch_build(gasm_batch* b, int k, uint64_t genome_len_hint) {
     API_GUARD_BEGIN
     if (!b) { gasm_set_error("batch is null"); return GASM_ERR_INVALID; }
-    b->built = false; b->paths_ready = false; b->ss.valid = false; b->ss.launched = false; b->scored = false;
-    GCHK(pipeline_build(b->ctx, b->rd, k, genome_len_hint, b->bs));
+    b->built = false; b->scored = false;
+    for (SubBatch& sb : b->sub) {
+        sb.paths_ready = false; sb.ss.valid = false; sb.ss.launched = false;
+        GCHK(pipeline_build(sb.cx, sb.rd, k, genome_len_hint, sb.bs));
+    }
     b->built = true;
     return GASM_OK;
     API_GUARD_END
@@ -321,39 +396,61 @@ int gasm_batch_score(gasm_batch* b, int kmer, const double* table) {
     API_GUARD_BEGIN
     if (!b || !table) { gasm_set_error("gasm_batch_score: null argument"); return GASM_ERR_INVALID; }
     if (!b->built) { gasm_set_error("gasm_batch_score before gasm_batch_build"); return GASM_ERR_STATE; }
-    if (!b->table_set || memcmp(b->table_copy.data(), table, GASM_TABLE_ROWS * sizeof(double)) != 0) {
-        GCHK(b->tb.set_standard(b->ctx, table));
+    const bool new_table = !b->table_given || memcmp(b->table_copy.data(), table, GASM_TABLE_ROWS * sizeof(double)) != 0;
+    if (new_table) {
         b->table_copy.assign(table, table + GASM_TABLE_ROWS);
-        b->table_set = true;
+        b->table_given = true;
     }
-    // reads shorter than k (or none): the general scorer, which sizes its tables on the host — after the build's report
-    const bool through_graph = pipeline_score_uses_graph(b->rd, b->bs);
-    if (!through_graph) GCHK(batch_finish(b));
-    if (!b->paths_ready) {
-        GCHK(pipeline_contig_paths(b->ctx, b->rd, b->bs, b->dp));
-        b->paths_ready = true;
+    for (SubBatch& sb : b->sub) {
+        if (new_table || !sb.table_set) {
+            GCHK(sb.tb.set_standard(sb.cx, table));
+            sb.table_set = true;
+        }
+        // reads shorter than k (or none): the general scorer, which sizes its tables on the host — after the build's report
+        const bool through_graph = pipeline_score_uses_graph(sb.rd, sb.bs);
+        if (!through_graph) GCHK(sub_finish(b, sb));
+        if (!sb.paths_ready) {
+            GCHK(pipeline_contig_paths(sb.cx, sb.rd, sb.bs, sb.dp));
+            sb.paths_ready = true;
+        }
+        if (!through_graph) pipeline_contig_paths_host(sb.rd, sb.bs, sb.dp);
+        GCHK(pipeline_score_launch(sb.cx, sb.rd, sb.dp, kmer, sb.tb, false, false, sb.ss, &sb.bs));
     }
-    if (!through_graph) pipeline_contig_paths_host(b->rd, b->bs, b->dp);
-    GCHK(pipeline_score_launch(b->ctx, b->rd, b->dp, kmer, b->tb, false, false, b->ss, &b->bs));
     b->scored = true;
     b->score_kmer = kmer;
     return GASM_OK;
     API_GUARD_END
 }
 
-uint64_t gasm_batch_total_kmers(const gasm_batch* b) { return b ? b->bs.n_kmers : 0; }
-uint64_t gasm_batch_total_reads(const gasm_batch* b) { return b ? b->rd.n_reads : 0; }
+uint64_t gasm_batch_total_kmers(const gasm_batch* b) {
+    u64 n = 0;
+    if (b) for (const SubBatch& sb : b->sub) n += sb.bs.n_kmers;
+    return n;
+}
+uint64_t gasm_batch_total_reads(const gasm_batch* b) { return b ? b->n_reads : 0; }
 
 int gasm_batch_fetch_distinct(gasm_batch* b, const uint64_t** seg_off, const uint64_t** keys, const uint32_t** mult, int* words) {
     API_GUARD_BEGIN
     if (!b || !seg_off || !keys || !mult || !words) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
     GCHK(batch_finish(b));
-    GCHK(pipeline_fetch_distinct(b->ctx, b->rd, b->bs));
-    *seg_off = b->bs.h_seg_doff.data();
-    *keys = b->bs.h_dk_key.data();
-    *mult = b->bs.h_dk_cnt.data();
-    *words = b->bs.words;
+    for (SubBatch& sb : b->sub) GCHK(pipeline_fetch_distinct(sb.cx, sb.rd, sb.bs));
+    *words = b->sub[0].bs.words;
+    if (b->sub.size() == 1) {
+        BuildState& bs = b->sub[0].bs;
+        *seg_off = bs.h_seg_doff.data(); *keys = bs.h_dk_key.data(); *mult = bs.h_dk_cnt.data();
+        return GASM_OK;
+    }
+    b->h_seg_doff.assign((size_t)b->n_segments + 1, 0);
+    b->h_dk_key.clear(); b->h_dk_cnt.clear();
+    u64 base = 0;
+    for (SubBatch& sb : b->sub) {
+        for (u32 s = sb.seg0; s <= sb.seg1; ++s) b->h_seg_doff[s] = base + sb.bs.h_seg_doff[s - sb.seg0];
+        base += sb.bs.d_total;
+        b->h_dk_key.insert(b->h_dk_key.end(), sb.bs.h_dk_key.begin(), sb.bs.h_dk_key.end());
+        b->h_dk_cnt.insert(b->h_dk_cnt.end(), sb.bs.h_dk_cnt.begin(), sb.bs.h_dk_cnt.end());
+    }
+    *seg_off = b->h_seg_doff.data(); *keys = b->h_dk_key.data(); *mult = b->h_dk_cnt.data();
     return GASM_OK;
     API_GUARD_END
 }
@@ -363,10 +460,24 @@ int gasm_batch_fetch_contigs(gasm_batch* b, const uint64_t** seg_contig_off, con
     if (!b || !seg_contig_off || !off || !data) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
     GCHK(batch_finish(b));
-    GCHK(pipeline_fetch_contigs(b->ctx, b->rd, b->bs));
-    *seg_contig_off = b->bs.h_seg_coff.data();
-    *off = b->bs.h_c_off.data();
-    *data = b->bs.h_contigs.data();
+    for (SubBatch& sb : b->sub) GCHK(pipeline_fetch_contigs(sb.cx, sb.rd, sb.bs));
+    if (b->sub.size() == 1) {
+        BuildState& bs = b->sub[0].bs;
+        *seg_contig_off = bs.h_seg_coff.data(); *off = bs.h_c_off.data(); *data = bs.h_contigs.data();
+        return GASM_OK;
+    }
+    b->h_seg_coff.assign((size_t)b->n_segments + 1, 0);
+    b->h_c_off.clear(); b->h_contigs.clear();
+    u64 cbase = 0, bbase = 0;
+    for (SubBatch& sb : b->sub) {
+        for (u32 s = sb.seg0; s <= sb.seg1; ++s) b->h_seg_coff[s] = cbase + sb.bs.h_seg_coff[s - sb.seg0];
+        for (u32 c = 0; c < sb.bs.n_contigs; ++c) b->h_c_off.push_back(bbase + sb.bs.h_c_off[c]);
+        cbase += sb.bs.n_contigs;
+        bbase += sb.bs.contig_bases;
+        b->h_contigs.insert(b->h_contigs.end(), sb.bs.h_contigs.begin(), sb.bs.h_contigs.end());
+    }
+    b->h_c_off.push_back(bbase);
+    *seg_contig_off = b->h_seg_coff.data(); *off = b->h_c_off.data(); *data = b->h_contigs.data();
     return GASM_OK;
     API_GUARD_END
 }
@@ -376,12 +487,24 @@ int gasm_batch_fetch_scores(gasm_batch* b, const double** bp_score, const double
     API_GUARD_BEGIN
     if (!b || !bp_score || !norm_by_break_freqs || !norm_by_len || !kmer_breaks || !sequence_len) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     GCHK(batch_finish(b));
-    GCHK(pipeline_score_fetch(b->ctx, b->ss));
-    *bp_score = b->ss.h_bp.data();
-    *norm_by_break_freqs = b->ss.h_nf.data();
-    *norm_by_len = b->ss.h_nl.data();
-    *kmer_breaks = b->ss.h_breaks.data();
-    *sequence_len = b->ss.h_len.data();
+    for (SubBatch& sb : b->sub) GCHK(pipeline_score_fetch(sb.cx, sb.ss));
+    if (b->sub.size() == 1) {
+        ScoreState& ss = b->sub[0].ss;
+        *bp_score = ss.h_bp.data(); *norm_by_break_freqs = ss.h_nf.data(); *norm_by_len = ss.h_nl.data();
+        *kmer_breaks = ss.h_breaks.data(); *sequence_len = ss.h_len.data();
+        return GASM_OK;
+    }
+    b->h_bp.clear(); b->h_nf.clear(); b->h_nl.clear(); b->h_breaks.clear(); b->h_len.clear();
+    for (SubBatch& sb : b->sub) {
+        ScoreState& ss = sb.ss;
+        b->h_bp.insert(b->h_bp.end(), ss.h_bp.begin(), ss.h_bp.end());
+        b->h_nf.insert(b->h_nf.end(), ss.h_nf.begin(), ss.h_nf.end());
+        b->h_nl.insert(b->h_nl.end(), ss.h_nl.begin(), ss.h_nl.end());
+        b->h_breaks.insert(b->h_breaks.end(), ss.h_breaks.begin(), ss.h_breaks.end());
+        b->h_len.insert(b->h_len.end(), ss.h_len.begin(), ss.h_len.end());
+    }
+    *bp_score = b->h_bp.data(); *norm_by_break_freqs = b->h_nf.data(); *norm_by_len = b->h_nl.data();
+    *kmer_breaks = b->h_breaks.data(); *sequence_len = b->h_len.data();
     return GASM_OK;
     API_GUARD_END
 }

@@ -60,6 +60,37 @@ int gasm_ctx::prof_collect() {
     return GASM_OK;
 }
 
+static gasm_ctx* ctx_new(int device, int n_cu) {
+    gasm_ctx* c = new gasm_ctx();
+    c->device = device;
+    c->n_cu = n_cu;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        gasm_set_error("hipStreamCreate failed");
+        return nullptr;
+    }
+    c->h_pin_words = 1 << 17;      // 1 MB: staging of small copies
+    if (hipHostMalloc((void**)&c->h_pin, c->h_pin_words * sizeof(u64), hipHostMallocCoherent) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        gasm_set_error("hipHostMalloc failed");
+        return nullptr;
+    }
+    return c;
+}
+
+gasm_ctx* gasm_ctx::lane(size_t i) {
+    while (lanes.size() <= i) {
+        if (hipSetDevice(device) != hipSuccess) return nullptr;
+        gasm_ctx* l = ctx_new(device, n_cu);
+        if (!l) return nullptr;
+        l->prof = prof;
+        l->prof_only = prof_only;
+        lanes.push_back(l);
+    }
+    return lanes[i];
+}
+
 extern "C" int gasm_ctx_create(int device, gasm_ctx** out) {
     if (!out) { gasm_set_error("gasm_ctx_create: out is null"); return GASM_ERR_INVALID; }
     *out = nullptr;
@@ -77,27 +108,16 @@ extern "C" int gasm_ctx_create(int device, gasm_ctx** out) {
         gasm_set_error("device %d is %s; libgasm is built for gfx950 only", device, prop.gcnArchName);
         return GASM_ERR_NO_DEVICE;
     }
-    gasm_ctx* c = new gasm_ctx();
-    c->device = device;
-    c->n_cu = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
-        gasm_set_error("hipStreamCreate failed");
-        return GASM_ERR_NO_DEVICE;
-    }
-    c->h_pin_words = 1 << 17;      // 1 MB: staging of small copies and the kernels' reports (3 words per segment)
-    if (hipHostMalloc((void**)&c->h_pin, c->h_pin_words * sizeof(u64), hipHostMallocCoherent) != hipSuccess) {
-        (void)hipStreamDestroy(c->stream);
-        delete c;
-        gasm_set_error("hipHostMalloc failed");
-        return GASM_ERR_NO_DEVICE;
-    }
+    gasm_ctx* c = ctx_new(device, prop.multiProcessorCount);
+    if (!c) return GASM_ERR_NO_DEVICE;
     *out = c;
     return GASM_OK;
 }
 
 extern "C" void gasm_ctx_destroy(gasm_ctx* c) {
     if (!c) return;
+    for (gasm_ctx* l : c->lanes) gasm_ctx_destroy(l);
+    c->lanes.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -110,6 +130,7 @@ extern "C" void gasm_ctx_destroy(gasm_ctx* c) {
 extern "C" int gasm_ctx_sync(gasm_ctx* c) {
     if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
     HIPCHK(hipStreamSynchronize(c->stream));
+    for (gasm_ctx* l : c->lanes) HIPCHK(hipStreamSynchronize(l->stream));
     return GASM_OK;
 }
 
@@ -119,6 +140,7 @@ extern "C" int gasm_profile_enable(gasm_ctx* c, int on) {
     if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
     if (!on && c->prof) GCHK(c->prof_collect());
     c->prof = on != 0;
+    for (gasm_ctx* l : c->lanes) GCHK(gasm_profile_enable(l, on));
     return GASM_OK;
 }
 
@@ -134,6 +156,7 @@ extern "C" int gasm_profile_filter(gasm_ctx* c, const char* names) {
             if (*p == 0) break;
         } else cur.push_back(*p);
     }
+    for (gasm_ctx* l : c->lanes) l->prof_only = c->prof_only;
     return GASM_OK;
 }
 
@@ -141,15 +164,27 @@ extern "C" int gasm_profile_reset(gasm_ctx* c) {
     if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
     GCHK(c->prof_collect());
     for (auto& s : c->stages) { s.ms = 0; s.launches = 0; }
+    for (gasm_ctx* l : c->lanes) GCHK(gasm_profile_reset(l));
     return GASM_OK;
 }
 
 extern "C" int gasm_profile_read(gasm_ctx* c, int* n, const char* const** names, const double** ms, const uint64_t** launches) {
     if (!c || !n || !names || !ms || !launches) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     GCHK(c->prof_collect());
+    // the lanes' stages are folded into this context's (same kernel names)
+    std::vector<ProfStage> all = c->stages;
+    for (gasm_ctx* l : c->lanes) {
+        GCHK(l->prof_collect());
+        for (auto& ls : l->stages) {
+            bool found = false;
+            for (auto& s : all) if (s.name == ls.name) { s.ms += ls.ms; s.launches += ls.launches; found = true; break; }
+            if (!found) all.push_back(ls);
+        }
+    }
+    c->out_stage_copy = all;
     c->out_names.clear(); c->out_ms.clear(); c->out_launches.clear();
-    for (auto& s : c->stages) { c->out_names.push_back(s.name.c_str()); c->out_ms.push_back(s.ms); c->out_launches.push_back(s.launches); }
-    *n = (int)c->stages.size();
+    for (auto& s : c->out_stage_copy) { c->out_names.push_back(s.name.c_str()); c->out_ms.push_back(s.ms); c->out_launches.push_back(s.launches); }
+    *n = (int)c->out_stage_copy.size();
     *names = c->out_names.data();
     *ms = c->out_ms.data();
     *launches = c->out_launches.data();

@@ -71,6 +71,10 @@ struct gasm_ctx {
     hipStream_t stream = nullptr;
     int n_cu = 256;
     bool lds_attrs_set = false;           // the > 64 KB dynamic-LDS opt-ins of this device's kernels (pipeline.hip)
+    // lanes: further streams of the same device on which a batch runs its sub-batches side by side (capi.hip).  A lane is
+    // a gasm_ctx of its own (stream, pinned area, profiler) owned by this one; sync / profile calls on the owner cover them.
+    std::vector<gasm_ctx*> lanes;
+    gasm_ctx* lane(size_t i);             // created on first use; nullptr on failure
     // small pinned host area for read-backs of counters/flags
     u64* h_pin = nullptr;
     size_t h_pin_words = 0;
@@ -89,6 +93,7 @@ struct gasm_ctx {
     std::vector<Pending> pending;
     std::vector<hipEvent_t> ev_pool;
     // read-out storage for gasm_profile_read
+    std::vector<ProfStage> out_stage_copy;
     std::vector<const char*> out_names;
     std::vector<double> out_ms;
     std::vector<u64> out_launches;

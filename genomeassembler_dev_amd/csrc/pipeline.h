@@ -61,6 +61,9 @@ struct BuildState {
     u64 D_cap = 0, maxD_cap = 0, bases_cap = 0;
     u32 maxD_est = 1, paths_est = 0;
     bool have_actual = false;               // maxD_est / paths_est / the partition come from a finished build of the same reads
+    // ---- optional stream choreography of sub-batches (capi.hip): wait for this event before the first kernel, record
+    // that one once the streaming kernels (partition + de-duplication) are queued
+    hipEvent_t ev_wait = nullptr, ev_streamed = nullptr;
     // ---- report: written by the last kernels of a build into pinned memory, read by pipeline_build_finish
     u32* h_report = nullptr;
     size_t h_report_words = 0;

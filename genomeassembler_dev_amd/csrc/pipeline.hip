@@ -611,7 +611,9 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         return GASM_OK;
     }
     distinct_caps(bs, S);
+    if (bs.ev_wait) HIPCHK(hipStreamWaitEvent(ctx->stream, bs.ev_wait, 0));
     GCHK(launch_distinct(ctx, rd, bs));
+    if (bs.ev_streamed) HIPCHK(hipEventRecord(bs.ev_streamed, ctx->stream));
     GCHK(launch_graph(ctx, S, bs));
     if (knobs().sync_build) GCHK(pipeline_build_finish(ctx, rd, bs, nullptr));
     return GASM_OK;

@@ -558,3 +558,35 @@ def test_alternating_batch_shapes_on_one_context(qtable):
             _check_segments_vs_oracle(b, reads, seg_off, genomes, range(n_seg), k, keys, prob)
         b.close()
     ctx.close()
+
+
+def test_sub_batches_on_lanes(qtable, monkeypatch):
+    """GASM_SUBBATCHES=3: a batch runs as three blocks of segments on three streams (lanes of the context), the blocks'
+    builds chained by stream events; fetched results are the concatenation, identical to the oracle's"""
+    keys, prob = qtable
+    monkeypatch.setenv("GASM_SUBBATCHES", "3")
+    n_seg, L, rl, cov, k = 11, 2500, 70, 20, 25
+    reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, cov, seed0=8100, planted=True)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    for _ in range(2):
+        b.build(k, genome_len_hint=L).score(8, prob)
+    assert b.total_kmers() == reads.shape[0] * (rl - k + 1)
+    contigs, sc = _check_batch_properties(b, seg_off, rl, k, n_seg)
+    _check_segments_vs_oracle(b, reads, seg_off, genomes, range(n_seg), k, keys, prob, contigs, sc)
+    b.close()
+    # ragged reads (general scorer) through the same split
+    rng = np.random.default_rng(5)
+    segs = []
+    for s in range(5):
+        g = _strs(synth.make_segment(8200 + s, 1500, planted=False)[None, :])[0]
+        segs.append([g[a:a + int(rng.integers(8, 60))] for a in rng.integers(0, 1440, 300)])
+    b = ga.SegmentBatch.from_strings(segs)
+    b.build(13).score(8, prob)
+    cs, sc = b.contigs(), b.scores()
+    for s, rs in enumerate(segs):
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, 13), 13, 1, rows=1)
+        assert cs[s] == ref["contigs"]
+        o = orc.calc_breakscore(cs[s], rs, "", 8, keys, prob, with_lev=False, with_freq=False)
+        a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+        _check_scores({kk: v[a:e] for kk, v in sc.items() if kk != "seg_contig_off"}, o, with_lev=False)
+    b.close()
