@@ -72,6 +72,20 @@ SYMBOLS = {
     "gasm_batch_fetch_distinct": (_int, [_vp, _PP, _PP, _PP, C.POINTER(_int)]),
     "gasm_batch_fetch_contigs": (_int, [_vp, _PP, _PP, _PP]),
     "gasm_batch_fetch_scores": (_int, [_vp, _PP, _PP, _PP, _PP, _PP]),
+    "gasm_pool_create": (_int, [_vp, _vp, _u64, _u32, _vp, _u32, _PP]),
+    "gasm_pool_free": (None, [_vp]),
+    "gasm_pool_key_words": (_int, [_vp]),
+    "gasm_pool_local_runs": (_int, [_vp, _int, _int, _PP]),
+    "gasm_pool_pack_runs": (_int, [_vp, _vp, _u64, _vp, _vp]),
+    "gasm_pool_merge_runs": (_int, [_vp, _u32, _u32, _vp, _vp, _vp, _vp, _PP]),
+    "gasm_pool_graph": (_int, [_vp, _u32]),
+    "gasm_pool_piece_words": (_int, [_vp, _u32, _u32, _vp]),
+    "gasm_pool_pack_reads": (_int, [_vp, _u32, _u32, _vp]),
+    "gasm_pool_set_reads": (_int, [_vp, _vp, _u64, _u32, _vp, _vp, _vp]),
+    "gasm_pool_score": (_int, [_vp, _int, _vp]),
+    "gasm_pool_fetch_distinct": (_int, [_vp, _PP, _PP, _PP, C.POINTER(_int)]),
+    "gasm_pool_fetch_contigs": (_int, [_vp, _PP, _PP, _PP]),
+    "gasm_pool_fetch_scores": (_int, [_vp, _PP, _PP, _PP, _PP, _PP]),
     "gasm_profile_enable": (_int, [_vp, _int]),
     "gasm_profile_filter": (_int, [_vp, C.c_char_p]),
     "gasm_profile_reset": (_int, [_vp]),
@@ -87,6 +101,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc, gfx950).  genomeassembler_dev_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own copy, and whichever copy initialises the GPU second finds
+        # no device.  When torch is part of the program (pooled builds, bench.py) it goes first.
+        import sys
+        if "torch" in sys.modules:
+            torch = sys.modules["torch"]
+            if torch.cuda.is_available():
+                torch.cuda.init()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)

@@ -9,13 +9,22 @@
 // Reads of all segments of a batch, packed 2-bit in one base stream.
 struct ReadSet {
     const u64* words;          // packed bases (+2 padding words)
-    const u64* read_off;       // n_reads+1 base offsets, or nullptr when fixed_len > 0
+    const u64* read_off;       // n_reads+1 base offsets; nullptr for fixed-length reads back to back; n_reads base positions
+                               // of fixed-length reads that do not lie back to back (read_span)
     const u64* seg_read_off;   // n_segments+1 read indices
     const u32* seg_tile_start; // n_segments+1 tile indices (depends on the tile width of the launch)
     const uint4* tile_info;    // per tile {segment, reads in the tile, first read lo, first read hi (16 bits) | offset round << 16}
     u32 fixed_len;
     u32 n_segments;
 };
+
+// Where read r lies in the packed stream.  Three layouts: ragged (read_off[n+1], fixed_len = 0), fixed length back to back
+// (read_off = nullptr), and fixed length at given base positions (read_off[n] with fixed_len > 0: the reads of a pooled
+// build arrive as word-aligned pieces from every rank, pipeline.hip "pool").
+__device__ __forceinline__ void read_span(const ReadSet& rs, u64 r, u64* p0, u32* len) {
+    if (rs.fixed_len) { *p0 = rs.read_off ? rs.read_off[r] : r * rs.fixed_len; *len = rs.fixed_len; }
+    else { const u64 a = rs.read_off[r]; *p0 = a; *len = (u32)(rs.read_off[r + 1] - a); }
+}
 
 // Sorted distinct k-mers (= distinct edges) of all segments, dense, with the per-(segment,bucket) directory.
 struct GraphView {
@@ -99,6 +108,15 @@ __global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* seg_cst
                                u64* c_off, u32 n_segments, u32 chunks);
 template <class K>
 __global__ void k_contig_emit(GraphView gv, const u64* link, const u64* e_coff, u8* out, u32 n_segments, u32 chunks);
+
+// ---- kernels_pool.hip
+template <class K>
+__global__ void k_pack_runs(const K* keys, const u32* mult, const u64* bstart, const u32* bucket_d, const u32* gb_list, const u64* dst_off, K* out_keys,
+                            u32* out_cnt);
+template <class K, int TBL>
+__global__ void k_bucket_merge(const K* in_keys, const u32* in_cnt, const u64* run_off, const u32* run_len, u32 n_src, K* out_keys, u32* out_cnt,
+                               const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits);
+__global__ void k_repack_reads(const u64* src, u64 b0, u64 b1, u64* words_out, u64 n_words);
 
 // ---- kernels_score.hip
 struct SeedTable {

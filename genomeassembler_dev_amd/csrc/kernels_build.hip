@@ -21,6 +21,7 @@
 #include "device_utils.h"
 #include "keyops.h"
 #include "kernels.h"
+#include "dedup_order.h"
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
@@ -81,11 +82,6 @@ __device__ __forceinline__ TileInfo tile_decode(const uint4* __restrict__ tinfo,
     ti.r0 = (u64)e.z | ((u64)(e.w & 0xFFFFu) << 32);
     ti.o = e.w >> 16;
     return ti;
-}
-
-__device__ __forceinline__ void read_span(const ReadSet& rs, u64 r, u64* p0, u32* len) {
-    if (rs.fixed_len) { *p0 = r * rs.fixed_len; *len = rs.fixed_len; }
-    else { const u64 a = rs.read_off[r]; *p0 = a; *len = (u32)(rs.read_off[r + 1] - a); }
 }
 
 // The words thread `tid` needs in tile `ti`, and how many of its KT starts are k-mers.
@@ -498,7 +494,6 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
                u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg, unsigned long long* __restrict__ stamps) {
     constexpr int LIMIT = TBL / 16 * 11;
     constexpr int BINS = TBL / 4;
-    constexpr int SL = TBL / GASM_WG;
     constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
     constexpr bool WIDE = sizeof(K) == 16;
     constexpr int LOG_SETS = LOG_TBL - 1;                     // sets of two slots
@@ -629,83 +624,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     }
     const u32 d = s_tmp[4];
     if ((dbg & 3) == 1 || (dbg & 3) == 2) { if (threadIdx.x == 0) bucket_d[bucket] = d; return; }
-    // ---- every thread pulls its slots (stride 256: conflict-free) into registers and bins them
-    const int bshift = low_bits > (LOG_TBL - 2) ? low_bits - (LOG_TBL - 2) : 0;
-    K rk[SL];
-    u32 rc[SL];
-#pragma unroll
-    for (int q = 0; q < SL; ++q) {
-        rk[q] = t_key[q * GASM_WG + threadIdx.x];
-        rc[q] = t_cnt[q * GASM_WG + threadIdx.x];
-        if (WIDE && rc[q] == 0) rk[q] = key_empty<K>();      // 128-bit tables mark free slots by the count
-        if (!kis_empty(rk[q])) atomicAdd(&s_start[kfield(rk[q], bshift) & (BINS - 1)], 1u);
-    }
-    __syncthreads();   // all table reads and all bin counts are done
-    {
-        constexpr int PER = BINS / GASM_WG;   // 4 or 2
-        u32 c[PER], sum = 0, mx = 0;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) { c[q] = s_start[threadIdx.x * PER + q]; sum += c[q]; mx = c[q] > mx ? c[q] : mx; }
-        u32 tot;
-        u32 ex = block_excl_scan<GASM_WG>(sum, s_tmp, &tot);
-#pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            s_start[threadIdx.x * PER + q] = ex;
-            s_cur[threadIdx.x * PER + q] = ex;
-            fdir[(u64)bucket * (BINS + 1) + threadIdx.x * PER + q] = (u16)ex;   // fine directory for the graph kernels
-            ex += c[q];
-        }
-        if (threadIdx.x == GASM_WG - 1) fdir[(u64)bucket * (BINS + 1) + BINS] = (u16)ex;
-        if (mx > 1) atomicMax(&s_tmp[6], mx);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < SL; ++q) {
-        if (!kis_empty(rk[q])) {
-            const u32 pos = atomicAdd(&s_cur[kfield(rk[q], bshift) & (BINS - 1)], 1u);
-            t_key[pos] = rk[q];
-            t_cnt[pos] = rc[q];
-        }
-    }
-    __syncthreads();
-    const u32 longest = s_tmp[6];
-    if (longest <= 24) {
-        // per-bin insertion sort (bins of 0/1 keys need nothing)
-        for (u32 b = threadIdx.x; b < (u32)BINS; b += GASM_WG) {
-            const u32 lo = s_start[b], hi = s_cur[b];
-            for (u32 i = lo + 1; i < hi; ++i) {
-                const K kx = t_key[i];
-                const u32 cx = t_cnt[i];
-                u32 j = i;
-                while (j > lo && kless(kx, t_key[j - 1])) { t_key[j] = t_key[j - 1]; t_cnt[j] = t_cnt[j - 1]; --j; }
-                t_key[j] = kx;
-                t_cnt[j] = cx;
-            }
-        }
-        __syncthreads();
-    } else {
-        // skewed keys: bitonic sort of the compacted entries
-        u32 p2 = 2;
-        while (p2 < d) p2 <<= 1;
-        for (u32 i = d + threadIdx.x; i < p2; i += GASM_WG) { t_key[i] = key_empty<K>(); t_cnt[i] = 0; }
-        __syncthreads();
-        for (u32 kk = 2; kk <= p2; kk <<= 1) {
-            for (u32 j = kk >> 1; j > 0; j >>= 1) {
-                for (u32 t = threadIdx.x; t < (p2 >> 1); t += GASM_WG) {
-                    const u32 lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const u32 hi = lo | j;
-                    const K a = t_key[lo], b = t_key[hi];
-                    const bool up = (lo & kk) == 0;
-                    if (kless(b, a) == up && !keq(a, b)) {
-                        t_key[lo] = b; t_key[hi] = a;
-                        const u32 ca = t_cnt[lo], cb = t_cnt[hi];
-                        t_cnt[lo] = cb; t_cnt[hi] = ca;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-    }
+    dedup_order<K, TBL>(t_key, t_cnt, s_start, s_cur, s_tmp, fdir, bucket, low_bits, d);
     phase(4);
     for (u32 i = threadIdx.x; i < d; i += GASM_WG) { keys[beg + i] = t_key[i]; mult[beg + i] = t_cnt[i]; }
     if (threadIdx.x == 0) bucket_d[bucket] = d;

@@ -1,0 +1,145 @@
+// kernels_pool.hip — kernels of the pooled (multi-GPU) build: SURVEY §8(e) mode 2.
+//
+// In a pooled build the reads of every segment are spread evenly over the ranks.  Each rank de-duplicates its own
+// k-mers per (segment, bucket) with the single-GPU kernels (kernels_build.hip); what it then holds per bucket is a sorted
+// run of distinct (key, count) records.  Runs travel between ranks (RCCL all-to-all, driven by the host layer) and
+// are combined where they arrive:
+//   k_pack_runs      the runs of a list of buckets, back to back in a send buffer (keys and counts as separate streams:
+//                    12 bytes per record for k <= 31, 20 for k <= 63 — the (segment, bucket) of a record is implied by
+//                    its position in a run directory both sides compute from the partition function);
+//   k_bucket_merge   all runs received for one bucket -> one sorted run with the counts added up + the bucket's fine
+//                    directory; same LDS table, same ordering code as k_bucket_dedup, with a count per insertion;
+//   k_repack_reads   a range of the packed read stream copied to a word boundary (the reads of a segment on their way
+//                    to the rank that scores the segment).
+// None of this is on the single-GPU hot path; the records are the ~cov-fold reduced output of the local de-duplication.
+#include "device_utils.h"
+#include "keyops.h"
+#include "kernels.h"
+#include "dedup_order.h"
+
+typedef unsigned long long u64x2p __attribute__((ext_vector_type(2)));
+
+// one workgroup per listed bucket: keys[bstart[gb] .. + bucket_d[gb]) -> out_keys[dst_off[i] ..)
+template <class K>
+__global__ void __launch_bounds__(GASM_WG) k_pack_runs(const K* __restrict__ keys, const u32* __restrict__ mult, const u64* __restrict__ bstart,
+                                                       const u32* __restrict__ bucket_d, const u32* __restrict__ gb_list,
+                                                       const u64* __restrict__ dst_off, K* __restrict__ out_keys, u32* __restrict__ out_cnt) {
+    const u32 gb = gb_list[blockIdx.x];
+    const u64 src = bstart[gb], dst = dst_off[blockIdx.x];
+    const u32 d = bucket_d[gb];
+    for (u32 i = threadIdx.x; i < d; i += GASM_WG) { out_keys[dst + i] = keys[src + i]; out_cnt[dst + i] = mult[src + i]; }
+}
+template __global__ void k_pack_runs<u64>(const u64*, const u32*, const u64*, const u32*, const u32*, const u64*, u64*, u32*);
+template __global__ void k_pack_runs<K128>(const K128*, const u32*, const u64*, const u32*, const u32*, const u64*, K128*, u32*);
+
+// ---- insertion with a count (the slow-path step of k_bucket_dedup, kernels_build.hip, generalised)
+#define GASM_SLOT_LOCKED 0xFFFFFFFFu
+template <int TBL>
+__device__ __forceinline__ bool merge_step(u64* t_key, u32* t_cnt, u32* n_distinct, u64 key, u32 w, u32& set) {
+    constexpr u32 NSETS = TBL / 2;
+    __asm__ volatile("" ::: "memory");
+    const u64x2p c = *reinterpret_cast<const u64x2p*>(&t_key[2 * set]);
+    int slot = c.x == key ? 0 : c.y == key ? 1 : -1;
+    if (slot < 0) {
+        const int emp = c.x == GASM_EMPTY64 ? 0 : c.y == GASM_EMPTY64 ? 1 : -1;
+        if (emp < 0) { set = (set + 1) & (NSETS - 1); return false; }
+        const u64 old = atomicCAS(reinterpret_cast<unsigned long long*>(&t_key[2 * set + emp]), (unsigned long long)GASM_EMPTY64,
+                                  (unsigned long long)key);
+        if (old == GASM_EMPTY64) atomicAdd(n_distinct, 1u);
+        else if (old != key) return false;       // someone else took the slot: look at the set again
+        slot = emp;
+    }
+    atomicAdd(&t_cnt[2 * set + slot], w);
+    return true;
+}
+// 128-bit keys: the slot's count word is the lock (0 free, LOCKED being written, else ready).  A record's count is never
+// 0 or LOCKED (a multiplicity of 2^32 - 1 is refused by the host: the counts are 32-bit).
+template <int TBL>
+__device__ __forceinline__ bool merge_step(K128* t_key, u32* t_cnt, u32* n_distinct, const K128& key, u32 w, u32& set) {
+    constexpr u32 NSETS = TBL / 2;
+    __asm__ volatile("" ::: "memory");
+    const uint2 c = *reinterpret_cast<const uint2*>(&t_cnt[2 * set]);
+    const u32 cc[2] = {c.x, c.y};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        if (cc[q] == GASM_SLOT_LOCKED) return false;
+        if (cc[q] == 0) {
+            if (atomicCAS(&t_cnt[2 * set + q], 0u, GASM_SLOT_LOCKED) != 0u) return false;
+            t_key[2 * set + q] = key;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __hip_atomic_store(&t_cnt[2 * set + q], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            atomicAdd(n_distinct, 1u);
+            return true;
+        }
+        __asm__ volatile("" ::: "memory");
+        const u64x2p kq = *reinterpret_cast<const u64x2p*>(&t_key[2 * set + q]);
+        if (kq.x == key.hi && kq.y == key.lo) { atomicAdd(&t_cnt[2 * set + q], w); return true; }
+    }
+    set = (set + 1) & (NSETS - 1);
+    return false;
+}
+
+// One workgroup per output bucket j.  Its inputs are n_src runs: run s lies at in_keys[run_off[j * n_src + s] ..) and has
+// run_len[j * n_src + s] records (0 = none).  Output: the merged sorted run at out_keys[bstart[j] ..) (capacity
+// bstart[j+1] - bstart[j] >= min(sum of the lengths, table limit)), its length in bucket_d[j], the fine directory of
+// bucket j.  *overflow is raised when the union does not fit the table (the partition needs more bucket bits).
+template <class K, int TBL>
+__global__ void __launch_bounds__(GASM_WG, 3)
+k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, const u64* __restrict__ run_off, const u32* __restrict__ run_len,
+               u32 n_src, K* __restrict__ out_keys, u32* __restrict__ out_cnt, const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
+               u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits) {
+    constexpr int LIMIT = TBL / 16 * 11;
+    constexpr int BINS = TBL / 4;
+    constexpr int LOG_SETS = (TBL == 4096 ? 12 : 11) - 1;
+    constexpr u32 NSETS = 1u << LOG_SETS;
+    __shared__ __align__(32) K t_key[TBL];
+    __shared__ __align__(16) u32 t_cnt[TBL];
+    __shared__ u32 s_start[BINS];
+    __shared__ u32 s_cur[BINS];
+    __shared__ u32 s_tmp[8];
+    const u32 j = blockIdx.x;
+    for (u32 i = threadIdx.x; i < TBL; i += GASM_WG) { t_key[i] = key_empty<K>(); t_cnt[i] = 0; }
+    for (u32 i = threadIdx.x; i < BINS; i += GASM_WG) s_start[i] = 0;
+    if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }
+    __syncthreads();
+    for (u32 s = 0; s < n_src; ++s) {
+        const u64 off = run_off[(u64)j * n_src + s];
+        const u32 len = run_len[(u64)j * n_src + s];
+        for (u32 i = threadIdx.x; i < len; i += GASM_WG) {
+            if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { s_tmp[5] = 1; break; }
+            const K key = in_keys[off + i];
+            const u32 w = in_cnt[off + i];
+            u32 st = khash(key) >> (32 - LOG_SETS);
+            bool ok = false;
+            for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = merge_step<TBL>(t_key, t_cnt, &s_tmp[4], key, w, st);
+            if (!ok) s_tmp[5] = 1;
+        }
+    }
+    __syncthreads();
+    if (s_tmp[5] || s_tmp[4] > (u32)LIMIT) {
+        if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[j] = 0; }
+        // (the fine directory of an overflowed bucket is never used: the caller repartitions)
+        return;
+    }
+    const u32 d = s_tmp[4];
+    dedup_order<K, TBL>(t_key, t_cnt, s_start, s_cur, s_tmp, fdir, j, low_bits, d);
+    const u64 beg = bstart[j];
+    for (u32 i = threadIdx.x; i < d; i += GASM_WG) { out_keys[beg + i] = t_key[i]; out_cnt[beg + i] = t_cnt[i]; }
+    if (threadIdx.x == 0) bucket_d[j] = d;
+}
+template __global__ void k_bucket_merge<u64, 4096>(const u64*, const u32*, const u64*, const u32*, u32, u64*, u32*, const u64*, u32*, u32*, u16*, int);
+template __global__ void k_bucket_merge<K128, 2048>(const K128*, const u32*, const u64*, const u32*, u32, K128*, u32*, const u64*, u32*, u32*, u16*, int);
+
+// words_out[w] = the 32 bases from base b0 + 32 w of the packed stream `src`, zero-filled past base b1; n_words words
+__global__ void __launch_bounds__(GASM_WG) k_repack_reads(const u64* __restrict__ src, u64 b0, u64 b1, u64* __restrict__ words_out, u64 n_words) {
+    for (u64 w = (u64)blockIdx.x * GASM_WG + threadIdx.x; w < n_words; w += (u64)gridDim.x * GASM_WG) {
+        const u64 p = b0 + 32 * w;
+        u64 v = 0;
+        if (p < b1) {
+            v = window32(src, p);
+            const u64 left = b1 - p;
+            if (left < 32) v &= ~0ull << (64 - 2 * left);
+        }
+        words_out[w] = v;
+    }
+}

@@ -51,8 +51,7 @@ __global__ void __launch_bounds__(GASM_WG) k_read_insert(ReadSet rs, SeedTable s
     const u64 r = rs.seg_read_off[seg] + (u64)blockIdx.x * GASM_WG + threadIdx.x;
     if (r >= rs.seg_read_off[seg + 1]) return;
     u64 p0; u32 len;
-    if (rs.fixed_len) { p0 = r * rs.fixed_len; len = rs.fixed_len; }
-    else { p0 = rs.read_off[r]; len = (u32)(rs.read_off[r + 1] - p0); }
+    read_span(rs, r, &p0, &len);
     if (len < (u32)w || len == 0) return;
     const u64 seed = kmer_at(rs.words, p0, w);
     const u64 tb = st.tbl_off[seg];
@@ -118,8 +117,7 @@ __global__ void __launch_bounds__(GASM_WG) k_path_scan(ReadSet rs, PathSet ps, S
         if (r == GASM_NONE32) break;
         if (st.seed[tb + h] != seed) continue;
         u64 p0; u32 len;
-        if (rs.fixed_len) { p0 = (u64)r * rs.fixed_len; len = rs.fixed_len; }
-        else { p0 = rs.read_off[r]; len = (u32)(rs.read_off[r + 1] - p0); }
+        read_span(rs, r, &p0, &len);
         if (g + len > pend) continue;
         if (!bases_equal(rs.words, p0, ps.words, g, len)) continue;
         atomicMin(&row[r - rfirst], (u32)g);
@@ -143,8 +141,7 @@ template <class K>
 __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& gv, const u64* __restrict__ link,
                                            const u32* __restrict__ e_cid, const PathSet& ps, u32 seg, u64 r, u32* path) {
     u64 p0; u32 len;
-    if (rs.fixed_len) { p0 = r * rs.fixed_len; len = rs.fixed_len; }
-    else { p0 = rs.read_off[r]; len = (u32)(rs.read_off[r + 1] - p0); }
+    read_span(rs, r, &p0, &len);
     if (len < (u32)gv.k) return ~0ull;
     const K key = kmer_key_at<K>(rs.words, p0, gv.k);
     u32 hi;

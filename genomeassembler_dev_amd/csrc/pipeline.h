@@ -13,6 +13,7 @@ struct DevReads {
     std::vector<u64> h_read_off;            // ragged only
     std::vector<u64> h_seg_read_off;        // n_segments+1
     std::vector<u64> h_seg_empty;           // empty reads per segment
+    bool positioned = false;                // fixed-length reads at the base positions in d_read_off (pooled builds)
     u64 upload_id = 0;                      // changes with every upload: "the same reads again?" (BuildState)
     DBuf d_words, d_read_off, d_seg_read_off;
     // tile directory cache (depends on reads per tile)
@@ -118,6 +119,12 @@ struct ScoreState {
 // queued behind the first attempt must be queued again).
 int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 genome_len_hint, BuildState& bs);
 int pipeline_build_finish(gasm_ctx* ctx, DevReads& rd, BuildState& bs, bool* rebuilt);
+int pipeline_build_finish_n(gasm_ctx* ctx, DevReads* rd, u32 n_segments, BuildState& bs, bool* rebuilt);
+// building blocks shared with the pooled build (pool.hip)
+int plan_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs);
+void distinct_caps(BuildState& bs, u32 n_segments);
+int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs);
+int launch_graph(gasm_ctx* ctx, u32 n_segments, BuildState& bs);
 int pipeline_fetch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs);
 int pipeline_fetch_contigs(gasm_ctx* ctx, DevReads& rd, BuildState& bs);
 // paths of the build as a DevPaths (packs the contig text on the device; works on a queued build); the host-side numbers

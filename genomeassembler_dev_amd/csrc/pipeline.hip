@@ -190,7 +190,7 @@ int DevReads::set_tiles(gasm_ctx* ctx, u32 ipt, u32 orr) {
 ReadSet DevReads::view() const {
     ReadSet v;
     v.words = d_words.as<u64>();
-    v.read_off = fixed_len ? nullptr : d_read_off.as<u64>();
+    v.read_off = (fixed_len && !positioned) ? nullptr : d_read_off.as<u64>();
     v.seg_read_off = d_seg_read_off.as<u64>();
     v.seg_tile_start = d_seg_tile_start.as<u32>();
     v.tile_info = d_tile_info.as<uint4>();
@@ -293,7 +293,7 @@ static int ensure_lds_attrs(gasm_ctx* ctx) {
 }
 
 // upper bound of the distinct k-mers of the segments, given the partition: a bucket holds at most `limit` (else it overflows)
-static void distinct_caps(BuildState& bs, u32 S) {
+void distinct_caps(BuildState& bs, u32 S) {
     const u64 limit = bs.small_tbl ? GASM_TBL_LIMIT / 2 : GASM_TBL_LIMIT;
     const u64 per_seg = ((u64)1 << bs.bbits) * limit;
     const u64 all = bs.k < 16 ? ((u64)1 << (2 * bs.k)) : ~(u64)0;     // 4^k different k-mers exist
@@ -319,7 +319,7 @@ static GraphView graph_view(const BuildState& bs) {
 }
 
 // ---- reads -> per-(segment, bucket) distinct k-mers with multiplicities (in place in d_keys / d_mult) + dstart
-static int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
+int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
     const int k = bs.k, W = bs.words, bbits = bs.bbits;
     const size_t KB = 8 * (size_t)W;
     const u32 S = rd.n_segments, nb = 1u << bbits, nbt = S * nb;
@@ -430,7 +430,7 @@ static int alloc_graph(BuildState& bs, u32 S) {
 
 // ---- dense arrays -> (k-1)-mer graph -> chains -> contigs + the report.  Inputs: d_keys/d_mult/d_bstart (the buckets'
 // distinct runs) and d_dstart/d_fdir.
-static int launch_graph(gasm_ctx* ctx, u32 S, BuildState& bs) {
+int launch_graph(gasm_ctx* ctx, u32 S, BuildState& bs) {
     const int W = bs.words, bbits = bs.bbits;
     const u32 nb = 1u << bbits, nbt = S * nb;
     GCHK(alloc_graph(bs, S));
@@ -528,7 +528,7 @@ static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
 }
 
 // host-side sizes of a batch's reads for key width / tile shape / bucket bits
-static int plan_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs) {
+int plan_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs) {
     if (k < 2 || k > GASM_MAX_K) { gasm_set_error("k = %d not supported (2..%d)", k, GASM_MAX_K); return GASM_ERR_INVALID; }
     const int W = k <= 31 ? 1 : 2;            // 64-bit keys up to k = 31, 128-bit keys (K128) up to k = 63
     const u32 KT = W == 1 ? 16u : 8u;         // k-mers per thread and round of the tile kernels (KeyTraits<K>::KT)
@@ -621,10 +621,14 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
 
 // Read the report of a queued build; repeat the build with the next larger configuration while it reports a failure.
 int pipeline_build_finish(gasm_ctx* ctx, DevReads& rd, BuildState& bs, bool* rebuilt) {
+    return pipeline_build_finish_n(ctx, &rd, rd.n_segments, bs, rebuilt);
+}
+
+// rd == nullptr: the dense arrays did not come from reads of this rank (pooled build): only the graph can be repeated
+int pipeline_build_finish_n(gasm_ctx* ctx, DevReads* rd, u32 S, BuildState& bs, bool* rebuilt) {
     if (rebuilt) *rebuilt = false;
     if (!bs.pending) return GASM_OK;
     HIPCHK(hipSetDevice(ctx->device));
-    const u32 S = rd.n_segments;
     for (;;) {
         const u32* const rep = bs.h_report;
         GCHK(wait_report(ctx, rep + 4 * (size_t)S + 6, bs.ticket));
@@ -633,6 +637,7 @@ int pipeline_build_finish(gasm_ctx* ctx, DevReads& rd, BuildState& bs, bool* reb
         if (!overflow && !rank_failed) break;
         if (rebuilt) *rebuilt = true;
         if (overflow) {
+            if (!rd) { gasm_set_error("a merged k-mer bucket overflowed its table: the pooled build needs more bucket bits"); return GASM_ERR_CAPACITY; }
             if (bs.small_tbl && bs.words == 1) bs.small_tbl = false;      // same partition, larger tables
             else {
                 if (bs.bbits >= bs.bb_cap) {
@@ -642,7 +647,7 @@ int pipeline_build_finish(gasm_ctx* ctx, DevReads& rd, BuildState& bs, bool* reb
                 bs.bbits = std::min(bs.bb_cap, bs.bbits + 2);
             }
             distinct_caps(bs, S);
-            GCHK(launch_distinct(ctx, rd, bs));
+            GCHK(launch_distinct(ctx, *rd, bs));
         } else {
             bs.rank_global = true;        // whole-GPU pointer doubling instead of the LDS ranking
         }

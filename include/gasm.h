@@ -174,6 +174,55 @@ int gasm_batch_fetch_contigs(gasm_batch* b, const uint64_t** seg_contig_off /*n_
 int gasm_batch_fetch_scores(gasm_batch* b, const double** bp_score, const double** norm_by_break_freqs,
                             const double** norm_by_len, const int32_t** kmer_breaks, const int32_t** sequence_len);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Pooled builds over several GPUs: the reads of every segment are spread over the ranks, k-mers are bucketed by
+ * (segment, first bits of the k-mer) and every bucket's records are brought together on one rank by an all-to-all before
+ * the global edge-list merge (SURVEY.md §8(e) mode 2; the reference has no counterpart: it loops over segments on one
+ * thread, scripts/02_Real_vs_rand_prob_own.R:33-53).  One gasm_pool per rank; the library does the device work of every
+ * stage and packs / consumes device buffers, the caller moves them between ranks (RCCL through its own runtime —
+ * genomeassembler_dev_amd/pooled.py uses torch.distributed — or plain copies between virtual ranks of one process) and
+ * decides which rank owns which bucket and which segment.  Records travel as two streams: keys (8 bytes for k <= 31, 16
+ * bytes hi:lo for k <= 63, sorted inside a run) and 32-bit counts; the bucket a run belongs to follows from its place in
+ * the bucket lists both sides derive from the ownership function.  Results do not depend on the number of ranks.
+ *
+ *   gasm_pool_create       this rank's reads (fixed length) of ALL n_segments segments
+ *   gasm_pool_local_runs   k-mers of those reads -> one sorted run of distinct (key, count) per bucket; bucket index =
+ *                          segment << bbits | first bbits bits of the k-mer; run_len (host, n_segments << bbits entries)
+ *   gasm_pool_pack_runs    the current runs of the listed buckets, back to back, into caller-owned device buffers
+ *   gasm_pool_merge_runs   n_out output buckets, each the union (counts added) of up to n_src runs found at record offset
+ *                          run_off[j * n_src + s], length run_len[j * n_src + s] (0 = none) of the input buffers; the
+ *                          merged runs become the pool's current runs (bucket index = j); merged_len: host, n_out entries
+ *   gasm_pool_graph        the current runs are the buckets of n_local segments (n_local << bbits, segment-major):
+ *                          graph, traversal, contigs of those segments (as gasm_batch_build)
+ *   gasm_pool_piece_words / gasm_pool_pack_reads   the 2-bit reads of segments [seg_lo, seg_hi) of this rank as
+ *                          word-aligned pieces, one per segment, back to back
+ *   gasm_pool_set_reads    the reads of the rank's own segments as received: piece i holds piece_reads[i] reads of local
+ *                          segment piece_seg[i] (non-decreasing) from word piece_word_off[i] of d_words
+ *   gasm_pool_score        as gasm_batch_score, for the rank's own segments
+ *   gasm_pool_fetch_*      as gasm_batch_fetch_*, for the rank's own segments
+ * GASM_ERR_CAPACITY from local_runs / merge_runs: a bucket holds too many distinct k-mers — use more bucket bits (all
+ * ranks must use the same bbits).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct gasm_pool gasm_pool;
+int gasm_pool_create(gasm_ctx* ctx, const char* reads, uint64_t n_reads, uint32_t fixed_len, const uint64_t* seg_read_off,
+                     uint32_t n_segments, gasm_pool** out);
+void gasm_pool_free(gasm_pool* p);
+int gasm_pool_key_words(const gasm_pool* p);   /* 64-bit words per key: 1 (k <= 31) or 2; valid after gasm_pool_local_runs */
+int gasm_pool_local_runs(gasm_pool* p, int k, int bbits, const uint32_t** run_len);
+int gasm_pool_pack_runs(gasm_pool* p, const uint32_t* bucket_ix, uint64_t n, void* d_keys_out, void* d_counts_out);
+int gasm_pool_merge_runs(gasm_pool* p, uint32_t n_out, uint32_t n_src, const uint64_t* run_off, const uint32_t* run_len,
+                         const void* d_keys_in, const void* d_counts_in, const uint32_t** merged_len);
+int gasm_pool_graph(gasm_pool* p, uint32_t n_local_segments);
+int gasm_pool_piece_words(gasm_pool* p, uint32_t seg_lo, uint32_t seg_hi, uint64_t* n_words /* seg_hi - seg_lo */);
+int gasm_pool_pack_reads(gasm_pool* p, uint32_t seg_lo, uint32_t seg_hi, void* d_words_out);
+int gasm_pool_set_reads(gasm_pool* p, const void* d_words, uint64_t n_words, uint32_t n_pieces, const uint32_t* piece_seg,
+                        const uint64_t* piece_reads, const uint64_t* piece_word_off);
+int gasm_pool_score(gasm_pool* p, int kmer, const double* table);
+int gasm_pool_fetch_distinct(gasm_pool* p, const uint64_t** seg_off, const uint64_t** keys, const uint32_t** mult, int* words);
+int gasm_pool_fetch_contigs(gasm_pool* p, const uint64_t** seg_contig_off, const uint64_t** off, const char** data);
+int gasm_pool_fetch_scores(gasm_pool* p, const double** bp_score, const double** norm_by_break_freqs, const double** norm_by_len,
+                           const int32_t** kmer_breaks, const int32_t** sequence_len);
+
 /* Per-kernel device time of the stages of build/score, accumulated with HIP events on the ctx stream since the last
  * reset (profiling on costs one event pair per launch).  names/ms/launches point into library storage. */
 int gasm_profile_enable(gasm_ctx* ctx, int on);

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the pooled-build tests move device buffers with torch: torch's HIP runtime has to be the one that initialises the GPU
+    # (genomeassembler_dev_amd/_lib.py), so it is imported before any test loads libgasm
+    if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
 
 
 @pytest.fixture(scope="session")
