@@ -116,7 +116,7 @@ __global__ void k_pack_runs(const K* keys, const u32* mult, const u64* bstart, c
 template <class K, int TBL>
 __global__ void k_bucket_merge(const K* in_keys, const u32* in_cnt, const u64* run_off, const u32* run_len, u32 n_src, K* out_keys, u32* out_cnt,
                                const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits);
-__global__ void k_repack_reads(const u64* src, u64 b0, u64 b1, u64* words_out, u64 n_words);
+__global__ void k_repack_reads(const u64* src, const u64* dir, u64* words_out);
 
 // ---- kernels_score.hip
 struct SeedTable {

@@ -115,7 +115,8 @@ int gasm_pool_local_runs(gasm_pool* p, int k, int bbits, const uint32_t** run_le
     }
     u64 maxNs = 0;
     for (u64 v : bs.h_seg_nk) maxNs = std::max(maxNs, v);
-    bs.small_tbl = bs.words == 2 || ((std::max<u64>(1, maxNs / 8) >> bbits) <= 900);
+    (void)maxNs;
+    bs.small_tbl = true;        // the caller chose bbits for buckets of <= ~900 distinct k-mers; a bucket that does not fit retries below
     for (int attempt = 0;; ++attempt) {
         distinct_caps(bs, S);
         GCHK(launch_distinct(ctx, p->rd, bs));
@@ -264,17 +265,23 @@ int gasm_pool_pack_reads(gasm_pool* p, uint32_t seg_lo, uint32_t seg_hi, void* d
     if (!p || seg_lo > seg_hi || seg_hi > p->rd.n_segments) { gasm_set_error("gasm_pool_pack_reads: bad argument"); return GASM_ERR_INVALID; }
     gasm_ctx* ctx = p->ctx;
     HIPCHK(hipSetDevice(ctx->device));
-    u64 woff = 0;
+    const u32 np = seg_hi - seg_lo;
+    if (np == 0) return GASM_OK;
+    std::vector<u64> dir((size_t)np * 3);
+    u64 woff = 0, max_words = 0;
     for (u32 s = seg_lo; s < seg_hi; ++s) {
         const u64 b0 = p->rd.h_seg_read_off[s] * (u64)p->rd.fixed_len, b1 = p->rd.h_seg_read_off[s + 1] * (u64)p->rd.fixed_len;
         const u64 nw = (b1 - b0 + 31) / 32;
-        if (nw) {
-            if (!d_words_out) { gasm_set_error("gasm_pool_pack_reads: null buffer"); return GASM_ERR_INVALID; }
-            GLAUNCH(ctx, "k_repack_reads", k_repack_reads, dim3(std::min<u32>(ceil_div_u64(nw, GASM_WG), (u32)ctx->n_cu * 8u)), dim3(GASM_WG), 0,
-                    p->rd.d_words.as<u64>(), b0, b1, static_cast<u64*>(d_words_out) + woff, nw);
-        }
+        dir[3 * (size_t)(s - seg_lo)] = b0; dir[3 * (size_t)(s - seg_lo) + 1] = b1; dir[3 * (size_t)(s - seg_lo) + 2] = woff;
         woff += nw;
+        max_words = std::max(max_words, nw);
     }
+    if (woff == 0) return GASM_OK;
+    if (!d_words_out) { gasm_set_error("gasm_pool_pack_reads: null buffer"); return GASM_ERR_INVALID; }
+    if (np > 65535) { gasm_set_error("at most 65535 pieces per call"); return GASM_ERR_CAPACITY; }
+    GCHK(up(ctx, p->d_off, dir.data(), dir.size() * 8));
+    GLAUNCH(ctx, "k_repack_reads", k_repack_reads, dim3(std::max(1u, std::min<u32>(ceil_div_u64(max_words, GASM_WG), 64u)), np), dim3(GASM_WG), 0,
+            p->rd.d_words.as<u64>(), p->d_off.as<u64>(), static_cast<u64*>(d_words_out));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return GASM_OK;
     POOL_GUARD_END

@@ -25,6 +25,7 @@
 // the reference root).
 // ============================================================================
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -506,6 +507,28 @@ uint64_t orc_time_build_score(const char* rd, const uint64_t* roff, uint64_t nr,
     for (int v : R.kmer_breaks) cs += (uint64_t)v;
     *checksum = cs + contigs.size();
     return km.size();
+}
+
+// The same work with its results handed back (bench.py's self-check and cpu_baseline leg in one call): tags 1 contigs,
+// 2 kmer_breaks(i32), 3 bp_score(f64), 4 [n_kmers](u64).  *seconds = time of the three stages alone
+// (steady_clock around k-mers + contigs + scoring; unpacking of the arguments and packing of the results excluded).
+unsigned char* orc_build_score(const char* rd, const uint64_t* roff, uint64_t nr, int k, int kmer, const char* kd,
+                               const uint64_t* koff, uint64_t nk, const double* prob, double* seconds, uint64_t* nbytes) {
+    orc::StrVec reads = unpack(rd, roff, nr);
+    orc::StrVec bpk = unpack(kd, koff, nk);
+    std::vector<double> bpp(prob, prob + nk);
+    const auto t0 = std::chrono::steady_clock::now();
+    orc::StrVec km = orc::kmers_from_reads(reads, k);
+    orc::StrVec contigs = orc::dbg_contigs(km, k, nullptr);
+    orc::BreakScores R = orc::calc_breakscore(contigs, reads, std::string(), kmer, bpk, bpp, false, false);
+    *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    Blob B;
+    B.strs(1, contigs);
+    B.vec(2, R.kmer_breaks);
+    B.vec(3, R.bp_score);
+    std::vector<uint64_t> n = {(uint64_t)km.size()};
+    B.vec(4, n);
+    return B.finish(nbytes);
 }
 
 // tags: 1 scaffolds.  matrix given as `rows` permutations (u32 indices) of `contigs`.

@@ -132,6 +132,23 @@ def time_build_score(reads, k, kmer, bp_kmer, bp_prob):
     return int(n), time.perf_counter() - t0
 
 
+def build_score(reads, k, kmer, bp_kmer, bp_prob):
+    """bench.py: k-mers -> contigs -> scores of one segment in one call, single thread (ctypes releases the GIL, so several
+    of these run side by side from Python threads).  Returns dict(n_kmers, seconds (the three stages alone), contigs,
+    kmer_breaks, bp_score)."""
+    rb, ro = _pack(reads)
+    kb, ko = _pack(bp_kmer)
+    prob = np.ascontiguousarray(bp_prob, dtype=np.float64)
+    sec, n = C.c_double(), C.c_uint64()
+    f = lib().orc_build_score
+    f.restype = C.c_void_p
+    p = f(rb, _p(ro), C.c_uint64(len(reads)), C.c_int(k), C.c_int(kmer), kb, _p(ko), C.c_uint64(len(bp_kmer)), _p(prob), C.byref(sec),
+          C.byref(n))
+    b = _blob(p, n.value)
+    return dict(n_kmers=int(np.frombuffer(b[4], dtype=np.uint64)[0]), seconds=sec.value, contigs=_strs(b[1]),
+                kmer_breaks=np.frombuffer(b[2], dtype=np.int32), bp_score=np.frombuffer(b[3], dtype=np.float64))
+
+
 def assemble_contigs(contigs, perm, dbg_kmer):
     """Restates assemble_contigs(contig_matrix, dbg_kmer) (lib/DeNovoAssembler.cpp:215-305); the matrix is given as
     `perm` (rows × len(contigs) indices)."""
