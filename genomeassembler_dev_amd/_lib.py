@@ -11,7 +11,7 @@ STATUS = {0: "GASM_OK", -1: "GASM_ERR_INVALID", -2: "GASM_ERR_NON_ACGT", -3: "GA
           -5: "GASM_ERR_CAPACITY", -6: "GASM_ERR_RANGE", -7: "GASM_ERR_STATE"}
 TABLE_ROWS = 69904
 SCORE_OWN, SCORE_VELVET = 0, 1
-WANT_LEV, WANT_FREQ = 1, 2
+WANT_LEV, WANT_FREQ, WANT_KS = 1, 2, 4
 
 
 class GasmError(RuntimeError):
@@ -61,9 +61,21 @@ SYMBOLS = {
     "gasm_scores_startpos": (_vp, [_vp]),
     "gasm_scores_prob_dist": (_vp, [_vp]),
     "gasm_scores_prob_dist_offsets": (_vp, [_vp]),
+    "gasm_scores_ks": (_vp, [_vp]),
+    "gasm_coverage_percent": (_int, [_vp, _vp, _vp, _u64, C.c_int64, _vp]),
     "gasm_scores_free": (None, [_vp]),
     "gasm_levenshtein": (_int, [_vp, _u64, _vp, _u64, _int, C.POINTER(_i32)]),
     "gasm_batch_create": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _u32, _PP]),
+    "gasm_batch_create_packed": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _u32, _PP]),
+    "gasm_batch_from_files": (_int, [_vp, _vp, _u32, _int, _PP, C.POINTER(_u64)]),
+    "gasm_read_files": (_int, [_vp, _u32, _int, _PP]),
+    "gasm_packed_n_reads": (_u64, [_vp]),
+    "gasm_packed_n_segments": (_u32, [_vp]),
+    "gasm_packed_words": (_vp, [_vp]),
+    "gasm_packed_read_off": (_vp, [_vp]),
+    "gasm_packed_seg_read_off": (_vp, [_vp]),
+    "gasm_packed_dropped": (_u64, [_vp]),
+    "gasm_packed_free": (None, [_vp]),
     "gasm_batch_free": (None, [_vp]),
     "gasm_batch_build": (_int, [_vp, _int, _u64]),
     "gasm_batch_score": (_int, [_vp, _int, _vp]),

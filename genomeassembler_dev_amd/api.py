@@ -175,9 +175,10 @@ def levenshtein(query, target, infix=False):
 
 
 def calc_breakscore(path, sequencing_reads, true_solution, kmer, bp_kmer, bp_prob, variant="own", with_lev=True,
-                    with_freq=True, ctx=None):
+                    with_freq=True, with_ks=False, ctx=None):
     """Returns a dict with the names of the reference's Rcpp::List (lib/DeNovoAssembler.cpp:467-476 /
-    lib/BreakageScorer.cpp:343-353).  path_freq rows follow bp_kmer order (the reference: hash order)."""
+    lib/BreakageScorer.cpp:343-353).  path_freq rows follow bp_kmer order (the reference: hash order).
+    with_ks adds stat_test_KS: what lib/DeNovoAssembler.R:419-424 computes from path_freq afterwards."""
     ctx = ctx or default_context()
     velvet = variant == "velvet"
     if variant not in ("own", "velvet"):
@@ -187,7 +188,7 @@ def calc_breakscore(path, sequencing_reads, true_solution, kmer, bp_kmer, bp_pro
     kb, ko = _pack(bp_kmer)
     prob = np.ascontiguousarray(bp_prob, dtype=np.float64)
     t = true_solution.encode() if isinstance(true_solution, str) else bytes(true_solution)
-    flags = (_lib.WANT_LEV if with_lev else 0) | (_lib.WANT_FREQ if with_freq and not velvet else 0)
+    flags = (_lib.WANT_LEV if with_lev else 0) | (_lib.WANT_FREQ if with_freq and not velvet else 0) | (_lib.WANT_KS if with_ks else 0)
     h = C.c_void_p()
     check(lib().gasm_calc_breakscore(ctx.h, pb, _ptr(po), len(path), rb, _ptr(ro), len(sequencing_reads), t, len(t), int(kmer),
                                      kb, _ptr(ko), len(bp_kmer), _ptr(prob), _lib.SCORE_VELVET if velvet else _lib.SCORE_OWN,
@@ -210,6 +211,19 @@ def calc_breakscore(path, sequencing_reads, true_solution, kmer, bp_kmer, bp_pro
         elif with_freq:
             f = _arr(L.gasm_scores_path_freq(h), C.c_double, n * len(bp_kmer))
             out["path_freq"] = f.reshape(n, len(bp_kmer))
+        if with_ks:
+            out["stat_test_KS"] = _arr(L.gasm_scores_ks(h), C.c_double, n)
     finally:
         L.gasm_scores_free(h)
     return out
+
+
+def coverage_percent(starts, lens, seq_len, ctx=None):
+    """contig_frac_len (lib/DeNovoAssembler.R:432-445): percentage of [1, seq_len] covered by the union of the inclusive
+    ranges [start, start + len]"""
+    ctx = ctx or default_context()
+    a = np.ascontiguousarray(starts, dtype=np.int64)
+    b = np.ascontiguousarray(lens, dtype=np.int64)
+    out = C.c_double()
+    check(lib().gasm_coverage_percent(ctx.h, _ptr(a), _ptr(b), len(a), int(seq_len), C.byref(out)))
+    return out.value

@@ -21,12 +21,18 @@ struct gasm_contigs {
     std::vector<u32> dmult;
 };
 
+struct gasm_packed {
+    gasm_host::PackedReads pr;
+    std::vector<u64> seg;
+    u64 dropped = 0;
+};
+
 struct gasm_scores {
     u64 n = 0;
     std::vector<int32_t> len, breaks, lev, startpos;
-    std::vector<double> bp, nf, nl, freq, pd;
+    std::vector<double> bp, nf, nl, freq, pd, ks;
     std::vector<u64> pd_off;
-    bool has_freq = false, velvet = false;
+    bool has_freq = false, velvet = false, has_ks = false;
 };
 
 // A batch runs as one or more sub-batches — contiguous blocks of its segments, each with its own reads, build and
@@ -245,6 +251,11 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
                 s->startpos[p] = (int32_t)(int)truth.find(pth);
             }
         }
+        if (flags & GASM_WANT_KS) {
+            // lib/DeNovoAssembler.R:414-424: ks.test(path_freq, kmer_from_seq)$statistic per path
+            st = pipeline_ks(ctx, dp, ss, tb, true_solution ? true_solution : "", true_len, kmer, s->ks);
+            s->has_ks = st == GASM_OK;
+        }
         bool lev_done = false;
         // GPU or host?  One wave walks a path's bands column by column (~0.25 us per column and band, whatever the number
         // of paths up to a few thousand), the host routine costs ~1.5 ns per 64 cells and runs 32 paths at a time: a
@@ -265,7 +276,7 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
             const double host_ms = cells / 64.0 * 1.5e-6 / (double)std::max<u64>(1, std::min<u64>(32, n_paths));
             lev_gpu = gpu_ms < host_ms;
         }
-        if ((flags & GASM_WANT_LEV) && lev_gpu) {
+        if (st == GASM_OK && (flags & GASM_WANT_LEV) && lev_gpu) {
             // lib/DeNovoAssembler.cpp:463 (global) / lib/BreakageScorer.cpp:339 (infix): one wave per path on the GPU
             st = pipeline_levenshtein(ctx, dp, true_solution, true_len, velvet, s->lev, &lev_done);
         }
@@ -308,6 +319,14 @@ const double* gasm_scores_path_freq(const gasm_scores* s) { return s && s->has_f
 const int32_t* gasm_scores_startpos(const gasm_scores* s) { return s && s->velvet ? s->startpos.data() : nullptr; }
 const double* gasm_scores_prob_dist(const gasm_scores* s) { return s && s->velvet ? s->pd.data() : nullptr; }
 const uint64_t* gasm_scores_prob_dist_offsets(const gasm_scores* s) { return s && s->velvet ? s->pd_off.data() : nullptr; }
+const double* gasm_scores_ks(const gasm_scores* s) { return s && s->has_ks ? s->ks.data() : nullptr; }
+
+int gasm_coverage_percent(gasm_ctx* ctx, const int64_t* start, const int64_t* len, uint64_t n, int64_t seq_len, double* percent) {
+    API_GUARD_BEGIN
+    if (!ctx || !percent || (n && (!start || !len))) { gasm_set_error("gasm_coverage_percent: null argument"); return GASM_ERR_INVALID; }
+    return pipeline_coverage(ctx, reinterpret_cast<const long long*>(start), reinterpret_cast<const long long*>(len), n, (long long)seq_len, percent);
+    API_GUARD_END
+}
 void gasm_scores_free(gasm_scores* s) { delete s; }
 
 // ------------------------------------------------------------------------------------------------------ batches
@@ -366,6 +385,81 @@ int gasm_batch_create(gasm_ctx* ctx, const char* reads, const uint64_t* read_off
     }
     *out = b;
     return GASM_OK;
+    API_GUARD_END
+}
+
+// one block on the context's own stream, from reads that are packed already
+static int batch_from_packed(gasm_ctx* ctx, const u64* words, const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off,
+                             u32 n_segments, gasm_batch** out) {
+    gasm_batch* b = new gasm_batch();
+    b->ctx = ctx;
+    b->n_segments = n_segments;
+    b->n_reads = n_reads;
+    b->sub.resize(1);
+    SubBatch& sb = b->sub[0];
+    sb.cx = ctx; sb.seg0 = 0; sb.seg1 = n_segments;
+    const int st = sb.rd.upload_packed(ctx, words, read_off, n_reads, fixed_len, seg_read_off, n_segments);
+    if (st != GASM_OK) { gasm_batch_free(b); return st; }
+    *out = b;
+    return GASM_OK;
+}
+
+int gasm_batch_create_packed(gasm_ctx* ctx, const uint64_t* words, const uint64_t* read_off, uint64_t n_reads, uint32_t fixed_len,
+                             const uint64_t* seg_read_off, uint32_t n_segments, gasm_batch** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out) { gasm_set_error("gasm_batch_create_packed: null argument"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    return batch_from_packed(ctx, words, read_off, n_reads, fixed_len, seg_read_off, n_segments, out);
+    API_GUARD_END
+}
+
+static int parse_files(const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_packed& g) {
+    g.pr.read_off.assign(1, 0);
+    g.seg.assign((size_t)n_files + 1, 0);
+    g.dropped = 0;
+    for (u32 f = 0; f < n_files; ++f) {
+        if (!paths[f]) { gasm_set_error("paths[%u] is null", f); return GASM_ERR_INVALID; }
+        u64 kept = 0;
+        GCHK(gasm_host::read_sequence_file(paths[f], on_non_acgt != 0, g.pr, &kept, &g.dropped));
+        g.seg[f + 1] = g.seg[f] + kept;
+    }
+    return GASM_OK;
+}
+
+int gasm_read_files(const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_packed** out) {
+    API_GUARD_BEGIN
+    if (!out || !paths || n_files == 0) { gasm_set_error("gasm_read_files: bad argument"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    gasm_packed* g = new gasm_packed();
+    const int st = parse_files(paths, n_files, on_non_acgt, *g);
+    if (st != GASM_OK) { delete g; return st; }
+    *out = g;
+    return GASM_OK;
+    API_GUARD_END
+}
+uint64_t gasm_packed_n_reads(const gasm_packed* g) { return g ? g->pr.read_off.size() - 1 : 0; }
+uint32_t gasm_packed_n_segments(const gasm_packed* g) { return g ? (uint32_t)(g->seg.size() - 1) : 0; }
+const uint64_t* gasm_packed_words(const gasm_packed* g) { return g ? g->pr.words.data() : nullptr; }
+const uint64_t* gasm_packed_read_off(const gasm_packed* g) { return g ? g->pr.read_off.data() : nullptr; }
+const uint64_t* gasm_packed_seg_read_off(const gasm_packed* g) { return g ? g->seg.data() : nullptr; }
+uint64_t gasm_packed_dropped(const gasm_packed* g) { return g ? g->dropped : 0; }
+void gasm_packed_free(gasm_packed* g) { delete g; }
+
+int gasm_batch_from_files(gasm_ctx* ctx, const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_batch** out, uint64_t* dropped_reads) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || !paths || n_files == 0) { gasm_set_error("gasm_batch_from_files: bad argument"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    gasm_packed g;
+    GCHK(parse_files(paths, n_files, on_non_acgt, g));
+    gasm_host::PackedReads& pr = g.pr;
+    std::vector<u64>& seg = g.seg;
+    if (dropped_reads) *dropped_reads = g.dropped;
+    const u64 n = pr.read_off.size() - 1;
+    // fixed-length reads (the usual case) need no offset array on the device
+    u32 flen = n ? (u32)std::min<u64>(pr.read_off[1], 0xFFFFFFFFull) : 0;
+    bool fixed = n > 0 && flen > 0;
+    for (u64 r = 0; fixed && r < n; ++r) fixed = pr.read_off[r + 1] - pr.read_off[r] == flen;
+    return batch_from_packed(ctx, pr.words.data(), fixed ? nullptr : pr.read_off.data(), n, fixed ? flen : 0, seg.data(), n_files, out);
     API_GUARD_END
 }
 

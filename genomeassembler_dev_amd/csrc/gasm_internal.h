@@ -131,4 +131,12 @@ void shuffle_perm(u64 n, int seed, u64 rows, std::vector<u32>& perm);
 int assemble(const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k, std::vector<std::string>& out);
 // Myers bit-parallel edit distance; infix = edlib HW mode, else NW.
 int levenshtein(const char* q, u64 nq, const char* t, u64 nt, bool infix);
+// reads of sequence files, packed 2-bit back to back (seqio.cpp)
+struct PackedReads {
+    std::vector<u64> words;        // 32 bases per word, first base most significant
+    std::vector<u64> read_off;     // n_reads + 1 base offsets (first entry 0)
+    u64 total_bases = 0;
+    void append(const std::string& seq);
+};
+int read_sequence_file(const char* path, bool error_on_non_acgt, PackedReads& out, u64* n_kept, u64* n_dropped);
 }  // namespace gasm_host

@@ -455,3 +455,166 @@ __global__ void __launch_bounds__(GASM_WG) k_levenshtein(PathSet ps, u32 n_paths
         if (ln == 0) out[p] = (int32_t)sc;
     }
 }
+
+// ================================================================================================================
+// F4 — the R post-processing of score_solutions() (lib/DeNovoAssembler.R:414-445): the two-sample Kolmogorov-Smirnov
+// statistic of a path's path_freq vector against the genome's per-position window probabilities (kmer_from_seq,
+// lib/GenerateReads.R:243-259), and the percentage of the genome covered by the solutions.
+//
+// Both samples of the KS test take their values from table rows: x_i = count_i / total for each of the n_table rows of
+// the path (most of them 0), y_j = prob(row of the genome window at j).  So neither vector is built: the genome side is a
+// histogram over rows, put into ascending-probability order and prefix-summed once per call (host, 70 k entries), and a
+// path's side is its per-row counts.  D = sup_t |Fx(t) - Fy(t)| is attained at a sample value; every distinct value of
+// either sample is evaluated with integer counts and one division per side (exact rationals in double; R accumulates
+// 1/n.x and -1/n.y in a cumsum, hence 1e-9 in the parity test, not bit equality).
+// ================================================================================================================
+// rows of the genome's kmer-long windows: hist[row] += 1 (windows absent from the table count nowhere: R's NA, dropped)
+__global__ void __launch_bounds__(GASM_WG) k_ks_genome_hist(const u64* __restrict__ gwords, u64 glen, int kmer, const int32_t* __restrict__ drow,
+                                                            u32* __restrict__ hist) {
+    if (kmer < 1 || kmer > 8 || glen < (u64)kmer) return;
+    const u64 n = glen - kmer + 1;
+    for (u64 p = (u64)blockIdx.x * GASM_WG + threadIdx.x; p < n; p += (u64)gridDim.x * GASM_WG) {
+        const int32_t row = drow[direct_base((u32)kmer) + (u32)kmer_at(gwords, p, kmer)];
+        if (row >= 0) atomicAdd(&hist[row], 1u);
+    }
+}
+
+// #{r : pv[r] <= t} over the ascending probabilities
+__device__ __forceinline__ u32 ks_rank_le(const double* __restrict__ pv, u32 n, double t) {
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (pv[m] <= t) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+// One workgroup per path (grid-stride over the paths).  scratch: two rows of n_table u32 per workgroup.
+//   pv[r]    the table's probabilities, ascending;  cumy[r] = genome windows with probability <= pv[r] (inclusive prefix
+//   sums in that order);  ny = cumy[n_table - 1]
+__global__ void __launch_bounds__(GASM_WG) k_path_ks(PathSet ps, const u32* __restrict__ poscnt, const int32_t* __restrict__ drow, int kmer,
+                                                     u32 n_table, const double* __restrict__ pv, const u32* __restrict__ cumy,
+                                                     u32* __restrict__ scratch, double* __restrict__ out, u32 n_paths) {
+    __shared__ u32 s_n[2];
+    __shared__ double s_best[GASM_WG / 64];
+    u32* const cnt = scratch + (u64)blockIdx.x * 2 * n_table;       // per-row counts of the path
+    u32* const srt = cnt + n_table;                                  // its non-zero counts, ascending
+    const u32 ny = n_table ? cumy[n_table - 1] : 0u;
+    for (u32 p = blockIdx.x; p < n_paths; p += gridDim.x) {
+        const u64 pb = ps.p_off[p];
+        const u32 len = (u32)(ps.p_off[p + 1] - pb);
+        for (u32 i = threadIdx.x; i < n_table; i += GASM_WG) cnt[i] = 0;
+        if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; }
+        __syncthreads();
+        u32 tot_local = 0;
+        for (u32 j = threadIdx.x; j < len; j += GASM_WG) {
+            const u32 c = poscnt[pb + j];
+            if (!c) continue;
+            tot_local += c;
+            u32 idx;
+            if (break_window(ps.words, pb, len, j, kmer, &idx)) {
+                const int32_t row = drow[idx];
+                if (row >= 0) atomicAdd(&cnt[row], c);
+            }
+        }
+        atomicAdd(&s_n[1], tot_local);
+        __syncthreads();
+        const u32 total = s_n[1];
+        // ---- the non-zero counts, compacted and sorted (bitonic, in the workgroup's scratch: L2-resident)
+        for (u32 i = threadIdx.x; i < n_table; i += GASM_WG) {
+            const u32 c = cnt[i];
+            if (c) srt[atomicAdd(&s_n[0], 1u)] = c;
+        }
+        __syncthreads();
+        const u32 nnz = s_n[0];
+        u32 p2 = 1;
+        while (p2 < nnz) p2 <<= 1;
+        for (u32 i = nnz + threadIdx.x; i < p2; i += GASM_WG) srt[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (u32 kk = 2; kk <= p2; kk <<= 1) {
+            for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (u32 t = threadIdx.x; t < (p2 >> 1); t += GASM_WG) {
+                    const u32 lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), hi = lo | jj;
+                    const u32 a = srt[lo], b = srt[hi];
+                    const bool up = (lo & kk) == 0;
+                    if ((a > b) == up) { srt[lo] = b; srt[hi] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        double best = 0.0;
+        if (total && ny && n_table) {
+            const double dnx = (double)n_table, dny = (double)ny, dtot = (double)total;
+            const u32 nzero = n_table - nnz;
+            // values of the path's sample: 0 (if any row is empty) and every distinct count / total
+            if (threadIdx.x == 0 && nzero) {
+                const u32 ry = ks_rank_le(pv, n_table, 0.0);
+                best = fabs((double)nzero / dnx - (ry ? (double)cumy[ry - 1] : 0.0) / dny);
+            }
+            for (u32 i = threadIdx.x; i < nnz; i += GASM_WG) {
+                if (i + 1 < nnz && srt[i + 1] == srt[i]) continue;         // last of a run of ties
+                const double t = (double)srt[i] / dtot;
+                const u32 ry = ks_rank_le(pv, n_table, t);
+                const double d = fabs((double)(nzero + i + 1) / dnx - (ry ? (double)cumy[ry - 1] : 0.0) / dny);
+                best = d > best ? d : best;
+            }
+            // values of the genome's sample: every distinct probability
+            for (u32 r = threadIdx.x; r < n_table; r += GASM_WG) {
+                if (r + 1 < n_table && pv[r + 1] == pv[r]) continue;
+                const double t = pv[r];
+                u32 lo = 0, hi = nnz;                                      // #{non-zero x <= t}, x = count / total in double
+                while (lo < hi) { const u32 m = (lo + hi) >> 1; if ((double)srt[m] / dtot <= t) lo = m + 1; else hi = m; }
+                const u32 cx = (t >= 0.0 ? nzero : 0u) + lo;
+                const double d = fabs((double)cx / dnx - (double)cumy[r] / dny);
+                best = d > best ? d : best;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+        if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double b = s_best[0];
+            for (int w = 1; w < GASM_WG / 64; ++w) b = s_best[w] > b ? s_best[w] : b;
+            out[p] = (total && ny && n_table) ? b : __builtin_nan("");      // nothing matched: path_freq is all NaN, R has no x
+        }
+        __syncthreads();
+    }
+}
+
+// Coverage: diff[a] += 1, diff[b + 1] -= 1 for the inclusive ranges [a, b] clipped to [1, seq_len]; a scan and a count of
+// the positive positions follow (k_cover_count: one workgroup, running carry).
+__global__ void __launch_bounds__(GASM_WG) k_cover_mark(const long long* __restrict__ start, const long long* __restrict__ len, u64 n, long long seq_len,
+                                                        int* __restrict__ diff) {
+    const u64 i = (u64)blockIdx.x * GASM_WG + threadIdx.x;
+    if (i >= n) return;
+    long long a = start[i], b = start[i] + len[i];
+    if (a < 1) a = 1;
+    if (b > seq_len) b = seq_len;
+    if (a > b) return;
+    atomicAdd(&diff[a], 1);
+    atomicAdd(&diff[b + 1], -1);
+}
+__global__ void __launch_bounds__(1024) k_cover_count(const int* __restrict__ diff, long long seq_len, unsigned long long* __restrict__ covered) {
+    __shared__ long long s_w[16];
+    __shared__ unsigned long long s_c[16];
+    const u32 ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long carry = 0;
+    unsigned long long cov = 0;
+    for (long long base = 1; base <= seq_len; base += 1024) {
+        const long long i = base + threadIdx.x;
+        const int v = i <= seq_len ? diff[i] : 0;
+        long long inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(inc, d, 64); if ((int)ln >= d) inc += o; }
+        if (ln == 63) s_w[wv] = inc;
+        __syncthreads();
+        long long before = 0, tot = 0;
+        for (u32 w = 0; w < 16; ++w) { if (w < wv) before += s_w[w]; tot += s_w[w]; }
+        __syncthreads();
+        if (i <= seq_len && carry + before + inc > 0) ++cov;
+        carry += tot;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cov += __shfl_xor(cov, d, 64);
+    if (ln == 0) s_c[wv] = cov;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 0; for (u32 w = 0; w < 16; ++w) t += s_c[w]; *covered = t; }
+}

@@ -23,6 +23,10 @@ struct DevReads {
 
     int upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off,
                u32 n_segments);
+    int upload_packed(gasm_ctx* ctx, const u64* words, const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off,
+                      u32 n_segments);
+    int set_layout(const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off, u32 n_segments);
+    int finish_upload(gasm_ctx* ctx);
     int set_tiles(gasm_ctx* ctx, u32 ipt, u32 orr);
     ReadSet view() const;
     u64 read_len(u64 r) const { return fixed_len ? fixed_len : h_read_off[r + 1] - h_read_off[r]; }
@@ -91,6 +95,7 @@ struct ScoreTable {
     // direct-address tables over ACGT strings of length 1..8 (87 380 rows)
     DBuf d_prob, d_row, d_fix;
     std::vector<double> h_prob;   // direct-address table as uploaded
+    std::vector<double> h_row_prob;   // the caller's table, row by row (KS statistic: rows in ascending-probability order)
     double h_absmax = 0;          // max |prob| (set with the table)
     int fix_shift = -1;           // d_fix = round(prob * 2^fix_shift), -1 = not built
     u32 n_table = 0;
@@ -139,4 +144,9 @@ int pipeline_score_fetch(gasm_ctx* ctx, ScoreState& ss);
 bool pipeline_score_uses_graph(const DevReads& rd, const BuildState& graph);
 // Levenshtein distance of every path of `dp` against `target` (ASCII) on the GPU (k_levenshtein).  *done = false when
 // the target holds a byte outside ACGT (the packed form cannot represent it): the caller then uses the host routine.
+// Two-sample KS statistic of every path's path_freq against the genome's per-position window probabilities
+// (lib/DeNovoAssembler.R:414-424); needs the position counters of a general (non-graph) pipeline_score_launch.
+int pipeline_ks(gasm_ctx* ctx, DevPaths& dp, ScoreState& ss, const ScoreTable& tb, const char* genome, u64 genome_len, int kmer, std::vector<double>& ks);
+// contig_frac_len (lib/DeNovoAssembler.R:432-445)
+int pipeline_coverage(gasm_ctx* ctx, const long long* start, const long long* len, u64 n, long long seq_len, double* percent);
 int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 target_len, bool infix, std::vector<int32_t>& lev, bool* done);

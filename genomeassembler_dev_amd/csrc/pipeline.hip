@@ -102,26 +102,24 @@ static int pack_ascii(gasm_ctx* ctx, const u8* d_ascii, u64 nbases, DBuf& words,
 // ---------------------------------------------------------------------------------------------------------------
 // DevReads
 // ---------------------------------------------------------------------------------------------------------------
-int DevReads::upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 n, u32 flen, const u64* seg_off, u32 S) {
-    if (!ctx) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
+// host-side layout of a batch's reads: per-segment directories, shortest / longest read, empty reads
+int DevReads::set_layout(const u64* read_off, u64 n, u32 flen, const u64* seg_off, u32 S) {
     if (S == 0 || !seg_off) { gasm_set_error("need at least one segment and seg_read_off"); return GASM_ERR_INVALID; }
     if (S > 65535) { gasm_set_error("at most 65535 segments per batch (got %u)", S); return GASM_ERR_CAPACITY; }
     if (!read_off && flen == 0 && n) { gasm_set_error("give read_off or fixed_len"); return GASM_ERR_INVALID; }
     if (seg_off[0] != 0 || seg_off[S] != n) { gasm_set_error("seg_read_off must run from 0 to n_reads"); return GASM_ERR_INVALID; }
     for (u32 s = 0; s < S; ++s) if (seg_off[s] > seg_off[s + 1]) { gasm_set_error("seg_read_off not monotone"); return GASM_ERR_INVALID; }
-    HIPCHK(hipSetDevice(ctx->device));
     n_segments = S; n_reads = n; fixed_len = read_off ? 0 : flen;
+    positioned = false;
     h_seg_read_off.assign(seg_off, seg_off + S + 1);
     h_seg_empty.assign(S, 0);
     n_empty = 0; min_len = 0; max_len = 0;
-    const char* base = reads;
     if (read_off) {
         h_read_off.resize(n + 1);
         for (u64 r = 0; r <= n; ++r) {
             if (r && read_off[r] < read_off[r - 1]) { gasm_set_error("read_off not monotone"); return GASM_ERR_INVALID; }
             h_read_off[r] = read_off[r] - read_off[0];
         }
-        base = reads + read_off[0];
         total_bases = h_read_off[n];
         u32 s = 0;
         for (u64 r = 0; r < n; ++r) {
@@ -137,6 +135,24 @@ int DevReads::upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 
         total_bases = n * (u64)flen;
         if (n) { min_len = max_len = flen; }
     }
+    return GASM_OK;
+}
+
+int DevReads::finish_upload(gasm_ctx* ctx) {
+    if (!fixed_len) GCHK(h2d(ctx, d_read_off, h_read_off.data(), (n_reads + 1) * 8));
+    GCHK(h2d(ctx, d_seg_read_off, h_seg_read_off.data(), ((size_t)n_segments + 1) * 8));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    tiles_ipt = 0;
+    static std::atomic<u64> uploads{0};
+    upload_id = ++uploads;
+    return GASM_OK;
+}
+
+int DevReads::upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 n, u32 flen, const u64* seg_off, u32 S) {
+    if (!ctx) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
+    GCHK(set_layout(read_off, n, flen, seg_off, S));
+    HIPCHK(hipSetDevice(ctx->device));
+    const char* base = read_off ? reads + read_off[0] : reads;
     if (n && !reads && total_bases) { gasm_set_error("reads is null"); return GASM_ERR_INVALID; }
     DBuf ascii, err;
     GCHK(err.ensure(8));
@@ -149,12 +165,28 @@ int DevReads::upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 
     ascii.release(); err.release();
     if (st != GASM_OK) return st;
     if (herr) { gasm_set_error("reads contain a base outside upper-case ACGT"); return GASM_ERR_NON_ACGT; }
-    if (!fixed_len) GCHK(h2d(ctx, d_read_off, h_read_off.data(), (n + 1) * 8));
-    GCHK(h2d(ctx, d_seg_read_off, h_seg_read_off.data(), (S + 1) * 8));
-    tiles_ipt = 0;
-    static std::atomic<u64> uploads{0};
-    upload_id = ++uploads;
-    return GASM_OK;
+    return finish_upload(ctx);
+}
+
+// Reads that are 2-bit packed already (first base most significant, 32 per word, back to back): a quarter of the bytes over
+// PCIe, no packing kernel.  Bits past the last base are ignored.
+int DevReads::upload_packed(gasm_ctx* ctx, const u64* words, const u64* read_off, u64 n, u32 flen, const u64* seg_off, u32 S) {
+    if (!ctx) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
+    GCHK(set_layout(read_off, n, flen, seg_off, S));
+    if (read_off && read_off[0] != 0) { gasm_set_error("packed reads: read_off must start at 0"); return GASM_ERR_INVALID; }
+    if (total_bases && !words) { gasm_set_error("words is null"); return GASM_ERR_INVALID; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const u64 nw = (total_bases + 31) / 32;
+    GCHK(d_words.ensure((nw + 4) * 8));
+    if (nw) HIPCHK(hipMemcpyAsync(d_words.p, words, nw * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(static_cast<char*>(d_words.p) + nw * 8, 0, 32, ctx->stream));
+    if (nw && (total_bases & 31)) {
+        // the tail of the last word must be zero (windows read past the last base)
+        const u64 last = words[nw - 1] & (~0ull << (64 - 2 * (total_bases & 31)));
+        HIPCHK(hipMemcpyAsync(static_cast<char*>(d_words.p) + (nw - 1) * 8, &last, 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return finish_upload(ctx);
 }
 
 // Tile table: a tile = up to ipt consecutive reads of one segment at one of orr offset rounds (kernels_build.hip, "Tiles").
@@ -760,6 +792,7 @@ int ScoreTable::set(gasm_ctx* ctx, const char* bp_kmer, const u64* bp_off, u64 n
         prob[idx] = bp_prob[i];
     }
     n_table = (u32)nt;
+    h_row_prob.assign(bp_prob, bp_prob + nt);
     GCHK(h2d(ctx, d_prob, prob.data(), prob.size() * 8));
     GCHK(h2d(ctx, d_row, row.data(), row.size() * 4));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -843,6 +876,73 @@ int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 ta
 }
 
 void ScoreTable::release() { d_prob.release(); d_row.release(); d_fix.release(); }
+
+// ---------------------------------------------------------------------------------------------------------------
+// F4: KS statistic and coverage (kernels_score.hip)
+// ---------------------------------------------------------------------------------------------------------------
+int pipeline_ks(gasm_ctx* ctx, DevPaths& dp, ScoreState& ss, const ScoreTable& tb, const char* genome, u64 genome_len, int kmer, std::vector<double>& ks) {
+    const u32 P = dp.n_paths, NT = tb.n_table;
+    ks.assign(P, std::nan(""));
+    if (P == 0) return GASM_OK;
+    if (tb.h_row_prob.size() != NT) { gasm_set_error("the KS statistic needs the table rows (ScoreTable::set)"); return GASM_ERR_STATE; }
+    HIPCHK(hipSetDevice(ctx->device));
+    DBuf ascii, err, gwords, hist, d_pv, d_cumy, scratch, d_out;
+    struct Rel { std::vector<DBuf*> v; ~Rel() { for (DBuf* b : v) b->release(); } } rel{{&ascii, &err, &gwords, &hist, &d_pv, &d_cumy, &scratch, &d_out}};
+    // ---- the genome's side: rows of its kmer-long windows, counted, in ascending-probability order, prefix-summed
+    GCHK(err.ensure(8));
+    HIPCHK(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+    GCHK(h2d(ctx, ascii, genome, genome_len));
+    GCHK(pack_ascii(ctx, ascii.as<u8>(), genome_len, gwords, err.as<u32>()));
+    GCHK(hist.ensure((size_t)std::max<u32>(NT, 1) * 4));
+    HIPCHK(hipMemsetAsync(hist.p, 0, (size_t)std::max<u32>(NT, 1) * 4, ctx->stream));
+    GLAUNCH(ctx, "k_ks_genome_hist", k_ks_genome_hist, dim3(std::max(1u, std::min<u32>(ceil_div_u64(genome_len + 1, GASM_WG), (u32)ctx->n_cu * 8u))), dim3(GASM_WG), 0,
+            gwords.as<u64>(), genome_len, kmer, tb.d_row.as<int32_t>(), hist.as<u32>());
+    std::vector<u32> h_hist(NT);
+    u32 herr = 0;
+    HIPCHK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (NT) HIPCHK(hipMemcpyAsync(h_hist.data(), hist.p, (size_t)NT * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (herr) { gasm_set_error("true_solution holds a base outside upper-case ACGT: the KS statistic needs its window probabilities"); return GASM_ERR_NON_ACGT; }
+    std::vector<u32> order(NT);
+    for (u32 i = 0; i < NT; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return tb.h_row_prob[a] < tb.h_row_prob[b]; });
+    std::vector<double> pv(NT);
+    std::vector<u32> cumy(NT);
+    u64 run = 0;
+    for (u32 r = 0; r < NT; ++r) { pv[r] = tb.h_row_prob[order[r]]; run += h_hist[order[r]]; cumy[r] = (u32)run; }
+    GCHK(h2d(ctx, d_pv, pv.data(), (size_t)NT * 8));
+    GCHK(h2d(ctx, d_cumy, cumy.data(), (size_t)NT * 4));
+    // ---- the paths' side
+    const u32 grid = std::min<u32>(P, (u32)ctx->n_cu * 2u);
+    GCHK(scratch.ensure((size_t)grid * 2 * std::max<u32>(NT, 1) * 4));
+    GCHK(d_out.ensure((size_t)P * 8));
+    GLAUNCH(ctx, "k_path_ks", k_path_ks, dim3(grid), dim3(GASM_WG), 0, dp.view(), ss.d_poscnt.as<u32>(), tb.d_row.as<int32_t>(), kmer, NT, d_pv.as<double>(),
+            d_cumy.as<u32>(), scratch.as<u32>(), d_out.as<double>(), P);
+    HIPCHK(hipMemcpyAsync(ks.data(), d_out.p, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GASM_OK;
+}
+
+int pipeline_coverage(gasm_ctx* ctx, const long long* start, const long long* len, u64 n, long long seq_len, double* percent) {
+    *percent = 0.0;
+    if (seq_len <= 0) return GASM_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    DBuf d_s, d_l, diff, cov;
+    struct Rel { std::vector<DBuf*> v; ~Rel() { for (DBuf* b : v) b->release(); } } rel{{&d_s, &d_l, &diff, &cov}};
+    GCHK(h2d(ctx, d_s, start, n * 8));
+    GCHK(h2d(ctx, d_l, len, n * 8));
+    GCHK(diff.ensure(((size_t)seq_len + 3) * 4));
+    GCHK(cov.ensure(8));
+    HIPCHK(hipMemsetAsync(diff.p, 0, ((size_t)seq_len + 3) * 4, ctx->stream));
+    if (n) GLAUNCH(ctx, "k_cover_mark", k_cover_mark, dim3(ceil_div_u64(n, GASM_WG)), dim3(GASM_WG), 0, d_s.as<long long>(), d_l.as<long long>(), n, seq_len, diff.as<int>());
+    GLAUNCH(ctx, "k_cover_count", k_cover_count, dim3(1), dim3(1024), 0, diff.as<int>(), seq_len, cov.as<unsigned long long>());
+    unsigned long long c = 0;
+    HIPCHK(hipMemcpyAsync(&c, cov.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // lib/DeNovoAssembler.R:445: (1 - uncovered / seq_len) * 100
+    *percent = (1.0 - (double)(seq_len - (long long)c) / (double)seq_len) * 100.0;
+    return GASM_OK;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // score: pipeline_score_launch queues everything on the stream; pipeline_score_fetch copies the results back.

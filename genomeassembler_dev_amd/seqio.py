@@ -1,75 +1,40 @@
 """FASTQ / FASTA in (the north star's "FASTQ-in" surface — the reference itself simulates its reads in
-R, lib/GenerateReads.R, and has no file reader on this path).  Host-side parsing only: the records are concatenated
-into the byte buffer + offsets that gasm_batch_create takes; packing to 2 bits happens on the GPU."""
-import gzip
+R, lib/GenerateReads.R, and has no file reader on this path).  The reader is libgasm's (csrc/seqio.cpp, C++ with zlib):
+it parses and packs 2-bit in one go; this module is its ctypes face."""
+import ctypes as C
 
 import numpy as np
 
-_ACGT = np.zeros(256, dtype=bool)
-_ACGT[[ord(c) for c in "ACGT"]] = True
+from ._lib import check, lib
 
 
-def _open(path):
-    return gzip.open(path, "rb") if str(path).endswith(".gz") else open(path, "rb")
+def _paths(paths):
+    arr = (C.c_char_p * len(paths))(*[str(p).encode() for p in paths])
+    return arr
 
 
-def read_sequences(path):
-    """Sequences of a FASTQ or FASTA file (plain or .gz), upper-cased, as a list of bytes.  FASTQ records are the
-    four-line kind sequencers write; FASTA sequences may span lines."""
-    out = []
-    with _open(path) as f:
-        first = f.read(1)
-        if not first:
-            return out
-        rest = f.read()
-    data = first + rest
-    lines = data.split(b"\n")
-    if first == b"@":
-        for i in range(0, len(lines) - 1, 4):
-            if not lines[i].startswith(b"@"):
-                if lines[i].strip() == b"":
-                    continue
-                raise ValueError(f"{path}: record {i // 4} does not start with '@'")
-            if i + 2 >= len(lines) or not lines[i + 2].startswith(b"+"):
-                raise ValueError(f"{path}: record {i // 4} has no '+' line (multi-line FASTQ is not supported)")
-            out.append(lines[i + 1].strip().upper())
-    elif first == b">":
-        cur = None
-        for ln in lines:
-            if ln.startswith(b">"):
-                if cur is not None:
-                    out.append(b"".join(cur).upper())
-                cur = []
-            elif cur is not None:
-                cur.append(ln.strip())
-        if cur is not None:
-            out.append(b"".join(cur).upper())
-    else:
-        raise ValueError(f"{path}: neither FASTQ ('@') nor FASTA ('>')")
-    return out
+def read_files(paths, non_acgt="drop"):
+    """one file per segment -> (words uint64 (2-bit, 32 bases per word, first base most significant, reads back to back),
+    read_off uint64[n+1] (base offsets), seg_read_off uint64[S+1], dropped reads)"""
+    h = C.c_void_p()
+    check(lib().gasm_read_files(_paths(paths), len(paths), 1 if non_acgt == "error" else 0, C.byref(h)))
+    L = lib()
+    try:
+        n, S = L.gasm_packed_n_reads(h), L.gasm_packed_n_segments(h)
+        off = np.ctypeslib.as_array(C.cast(L.gasm_packed_read_off(h), C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+        seg = np.ctypeslib.as_array(C.cast(L.gasm_packed_seg_read_off(h), C.POINTER(C.c_uint64)), shape=(S + 1,)).copy()
+        nw = (int(off[-1]) + 31) // 32
+        words = np.ctypeslib.as_array(C.cast(L.gasm_packed_words(h), C.POINTER(C.c_uint64)), shape=(nw,)).copy() if nw else np.zeros(0, np.uint64)
+        return words, off, seg, int(L.gasm_packed_dropped(h))
+    finally:
+        L.gasm_packed_free(h)
 
 
-def segments_from_files(paths, non_acgt="drop"):
-    """One file per segment -> (reads uint8, read_off uint64[n+1], seg_read_off uint64[S+1], dropped).
-    non_acgt: 'drop' removes reads holding a base outside ACGT (N, IUPAC codes) and counts them in `dropped`;
-    'error' raises instead (the packing kernel accepts ACGT only, as the reference's k-mer tables do)."""
-    seg = np.zeros(len(paths) + 1, dtype=np.uint64)
-    chunks, lens, dropped = [], [], 0
-    for s, p in enumerate(paths):
-        kept = 0
-        for r in read_sequences(p):
-            a = np.frombuffer(r, dtype=np.uint8)
-            if a.size and not _ACGT[a].all():
-                if non_acgt == "error":
-                    raise ValueError(f"{p}: read with a base outside ACGT")
-                dropped += 1
-                continue
-            chunks.append(a)
-            lens.append(a.size)
-            kept += 1
-        seg[s + 1] = seg[s] + kept
-    off = np.zeros(len(lens) + 1, dtype=np.uint64)
-    if lens:
-        off[1:] = np.cumsum(np.array(lens, dtype=np.uint64))
-    reads = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8)
-    return reads, off, seg, dropped
+def unpack_reads(words, read_off):
+    """packed reads -> list of bytes (for inspection and tests)"""
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n = int(read_off[-1])
+    w = np.asarray(words, dtype=np.uint64)
+    idx = np.arange(n)
+    bases = lut[((w[idx >> 5] >> (62 - 2 * (idx & 31)).astype(np.uint64)) & np.uint64(3)).astype(np.int64)] if n else np.zeros(0, np.uint8)
+    return [bases[int(read_off[i]):int(read_off[i + 1])].tobytes() for i in range(len(read_off) - 1)]

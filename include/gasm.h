@@ -120,6 +120,7 @@ void gasm_strlist_free(gasm_strlist* s);
 #define GASM_SCORE_VELVET 1
 #define GASM_WANT_LEV 1
 #define GASM_WANT_FREQ 2
+#define GASM_WANT_KS 4       /* stat_test_KS per path: lib/DeNovoAssembler.R:414-424 (own variant; true_solution must be ACGT) */
 int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_off, uint64_t n_paths,
                          const char* reads, const uint64_t* read_off, uint64_t n_reads, const char* true_solution,
                          uint64_t true_len, int kmer, const char* bp_kmer, const uint64_t* bp_off, uint64_t n_table,
@@ -135,7 +136,15 @@ const double* gasm_scores_path_freq(const gasm_scores* s);          /* count*n_t
 const int32_t* gasm_scores_startpos(const gasm_scores* s);          /* velvet variant, else NULL */
 const double* gasm_scores_prob_dist(const gasm_scores* s);          /* velvet: concatenated, see offsets */
 const uint64_t* gasm_scores_prob_dist_offsets(const gasm_scores* s);/* count+1 */
+/* two-sample Kolmogorov-Smirnov statistic D of the path's path_freq (NaN entries dropped) against the probabilities of
+ * the true solution's kmer-long windows (kmer_from_seq, lib/GenerateReads.R:243-259): what ks.test(...)$statistic gives in
+ * lib/DeNovoAssembler.R:419-424; NaN where no read matched (R stops with an error there).  NULL without GASM_WANT_KS. */
+const double* gasm_scores_ks(const gasm_scores* s);
 void gasm_scores_free(gasm_scores* s);
+
+/* contig_frac_len of lib/DeNovoAssembler.R:432-445: percentage of [1, seq_len] covered by the union of the inclusive
+ * ranges [start_i, start_i + len_i] (GRanges reduce + setdiff). */
+int gasm_coverage_percent(gasm_ctx* ctx, const int64_t* start, const int64_t* len, uint64_t n, int64_t seq_len, double* percent);
 
 /* Levenshtein distance as the reference takes it from edlib (lib/DeNovoAssembler.cpp:41-55 global,
  * lib/BreakageScorer.cpp:41-55 infix); 0 for an empty operand, like the reference's failure branch. */
@@ -158,6 +167,27 @@ int gasm_levenshtein(const char* query, uint64_t nq, const char* target, uint64_
  * ---------------------------------------------------------------------------------------------------------------- */
 int gasm_batch_create(gasm_ctx* ctx, const char* reads, const uint64_t* read_off, uint64_t n_reads, uint32_t fixed_len,
                       const uint64_t* seg_read_off, uint32_t n_segments, gasm_batch** out);
+/* the same from reads that are 2-bit packed already: A=0 C=1 G=2 T=3, first base in the two most significant bits of words[0],
+ * 32 bases per word, reads back to back (read i = bases [read_off[i], read_off[i+1]), or i * fixed_len); a quarter of the
+ * bytes over PCIe and no packing kernel */
+int gasm_batch_create_packed(gasm_ctx* ctx, const uint64_t* words, const uint64_t* read_off, uint64_t n_reads, uint32_t fixed_len,
+                             const uint64_t* seg_read_off, uint32_t n_segments, gasm_batch** out);
+/* FASTQ / FASTA in: one file per segment (FASTQ with four-line records, FASTA with one- or multi-line sequences, plain or
+ * gzip; lower case folded to upper case).  The reference has no reader of its own on this path (reads are simulated in R
+ * and written as FASTA, lib/GenerateReads.R:405-433).  on_non_acgt: 0 = reads holding a byte outside ACGT are dropped and
+ * counted in *dropped_reads, 1 = GASM_ERR_NON_ACGT.  The host packs 2-bit while it parses. */
+int gasm_batch_from_files(gasm_ctx* ctx, const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_batch** out,
+                          uint64_t* dropped_reads);
+/* the reader alone (host only, no GPU needed): the reads of the files, packed as gasm_batch_create_packed takes them */
+typedef struct gasm_packed gasm_packed;
+int gasm_read_files(const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_packed** out);
+uint64_t gasm_packed_n_reads(const gasm_packed* g);
+uint32_t gasm_packed_n_segments(const gasm_packed* g);
+const uint64_t* gasm_packed_words(const gasm_packed* g);
+const uint64_t* gasm_packed_read_off(const gasm_packed* g);        /* n_reads + 1 */
+const uint64_t* gasm_packed_seg_read_off(const gasm_packed* g);    /* n_segments + 1 */
+uint64_t gasm_packed_dropped(const gasm_packed* g);
+void gasm_packed_free(gasm_packed* g);
 void gasm_batch_free(gasm_batch* b);
 /* genome_len_hint: expected distinct k-mers per segment (0 = derive from the k-mer count); only sizes buckets */
 int gasm_batch_build(gasm_batch* b, int k, uint64_t genome_len_hint);

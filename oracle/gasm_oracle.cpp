@@ -26,6 +26,7 @@
 // ============================================================================
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -586,6 +587,59 @@ void orc_normalise_tables(double* prob, const uint64_t* sizes, uint64_t ntables)
     std::vector<double> v(prob, prob + tot);
     orc::normalise_tables(v, sz);
     std::memcpy(prob, v.data(), tot * 8);
+}
+
+// ---------------------------------------------------------------------------
+// F4 — the R post-processing of score_solutions() (lib/DeNovoAssembler.R:318-479).
+// ---------------------------------------------------------------------------
+// lib/GenerateReads.R:243-259: kmer_from_seq = probability of the kmer-long window starting at every genome position
+// (match() against the kmer-long table; a window absent from the table gives NA — not with ACGT input).
+void orc_kmer_from_seq(const char* genome, uint64_t len, int kmer, const char* kd, const uint64_t* koff, uint64_t nk,
+                       const double* prob, double* out /* len - kmer + 1 */) {
+    std::unordered_map<std::string, double> t;
+    orc::StrVec keys = unpack(kd, koff, nk);
+    for (uint64_t i = 0; i < nk; ++i) if ((int)keys[i].size() == kmer) t.emplace(keys[i], prob[i]);
+    const std::string g(genome, len);
+    for (uint64_t p = 0; p + kmer <= len; ++p) {
+        auto it = t.find(g.substr(p, kmer));
+        out[p] = it == t.end() ? std::nan("") : it->second;
+    }
+}
+
+// lib/DeNovoAssembler.R:414-424: NAs dropped from x, then stats::ks.test(x, y, "two.sided")$statistic, restated from
+// R's C-free R code for the two-sample case (stats:::ks.test.default, R 4.x):
+//     w <- c(x, y); z <- cumsum(ifelse(order(w) <= n.x, 1 / n.x, -1 / n.y))
+//     if (length(unique(w)) < (n.x + n.y)) z <- z[c(which(diff(sort(w)) != 0), n.x + n.y)]
+//     STATISTIC <- max(abs(z))
+// (y's NAs are dropped as well; an empty x or y is an error in R: NaN here.)  The p-value is not restated: parity unpinned.
+double orc_ks_statistic(const double* x, uint64_t nx0, const double* y, uint64_t ny0) {
+    std::vector<std::pair<double, int>> w;
+    uint64_t nx = 0, ny = 0;
+    for (uint64_t i = 0; i < nx0; ++i) if (!std::isnan(x[i])) { w.emplace_back(x[i], 0); ++nx; }
+    for (uint64_t i = 0; i < ny0; ++i) if (!std::isnan(y[i])) { w.emplace_back(y[i], 1); ++ny; }
+    if (nx == 0 || ny == 0) return std::nan("");
+    std::stable_sort(w.begin(), w.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first < b.first; });
+    const double ux = 1.0 / (double)nx, uy = -1.0 / (double)ny;
+    double z = 0, best = 0;
+    for (size_t i = 0; i < w.size(); ++i) {
+        z += w[i].second == 0 ? ux : uy;
+        if (i + 1 == w.size() || w[i + 1].first != w[i].first) best = std::max(best, std::fabs(z));   // last of a run of ties
+    }
+    return best;
+}
+
+// lib/DeNovoAssembler.R:432-445: percentage of [1, seq_len] covered by the union of the inclusive ranges
+// [start_i, start_i + len_i] (IRanges: start/end inclusive; `end = path_freq_startpos + sequence_len`).
+double orc_coverage_percent(const int64_t* start, const int64_t* len, uint64_t n, int64_t seq_len) {
+    if (seq_len <= 0) return 0.0;
+    std::vector<char> cov((size_t)seq_len + 2, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        const int64_t a = std::max<int64_t>(1, start[i]), b = std::min<int64_t>(seq_len, start[i] + len[i]);
+        for (int64_t p = a; p <= b; ++p) cov[(size_t)p] = 1;
+    }
+    int64_t unc = 0;
+    for (int64_t p = 1; p <= seq_len; ++p) unc += !cov[(size_t)p];
+    return (1.0 - (double)unc / (double)seq_len) * 100.0;
 }
 
 }  // extern "C"

@@ -221,3 +221,31 @@ def normalise_tables(prob, sizes):
     s = np.array(sizes, dtype=np.uint64)
     lib().orc_normalise_tables(_p(p), _p(s), C.c_uint64(len(s)))
     return p
+
+
+def kmer_from_seq(genome, kmer, bp_kmer, bp_prob):
+    """lib/GenerateReads.R:243-259: per-position probability of the genome's kmer-long windows"""
+    g = genome.encode() if isinstance(genome, str) else bytes(genome)
+    kb, ko = _pack(bp_kmer)
+    prob = np.ascontiguousarray(bp_prob, dtype=np.float64)
+    out = np.zeros(max(len(g) - kmer + 1, 0), dtype=np.float64)
+    lib().orc_kmer_from_seq(g, C.c_uint64(len(g)), C.c_int(kmer), kb, _p(ko), C.c_uint64(len(bp_kmer)), _p(prob), _p(out))
+    return out
+
+
+def ks_statistic(x, y):
+    """lib/DeNovoAssembler.R:414-424: D of R's two-sample ks.test after dropping NAs (NaN for an empty sample)"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    f = lib().orc_ks_statistic
+    f.restype = C.c_double
+    return f(_p(x), C.c_uint64(len(x)), _p(y), C.c_uint64(len(y)))
+
+
+def coverage_percent(starts, lens, seq_len):
+    """lib/DeNovoAssembler.R:432-445: contig_frac_len"""
+    a = np.ascontiguousarray(starts, dtype=np.int64)
+    b = np.ascontiguousarray(lens, dtype=np.int64)
+    f = lib().orc_coverage_percent
+    f.restype = C.c_double
+    return f(_p(a), _p(b), C.c_uint64(len(a)), C.c_int64(seq_len))

@@ -108,24 +108,51 @@ def test_assemble_index_merge_randomised_against_oracle():
 
 
 def test_fastq_fasta_reader(tmp_path):
+    """libgasm's C++ reader (csrc/seqio.cpp, host only: runs without a GPU) against the Python restatement in
+    oracle/seq_oracle.py, record by record: FASTQ with header extras and '@' in the qualities, lower case, a read with an N,
+    CRLF line ends, gzipped multi-line FASTA, blank lines, an empty file, a file without a final newline"""
     import gzip
+
+    import numpy as np
+
     from genomeassembler_dev_amd import seqio
+    from oracle import seq_oracle
     fq = tmp_path / "a.fastq"
-    fq.write_text("@r1\nACGTAC\n+\nIIIIII\n@r2 extra\nacgtn\n+r2\nIIIII\n@r3\nTTTT\n+\n@@@@\n")
+    fq.write_text("@r1\nACGTAC\n+\nIIIIII\n@r2 extra\nacgtn\n+r2\nIIIII\n@r3\nTTTT\n+\n@@@@\n\n")
     fa = tmp_path / "b.fa.gz"
     with gzip.open(fa, "wb") as f:
-        f.write(b">c1\nACG\nTAC\n>c2\nGGGG\n")
-    assert seqio.read_sequences(fq) == [b"ACGTAC", b"ACGTN", b"TTTT"]
-    assert seqio.read_sequences(fa) == [b"ACGTAC", b"GGGG"]
-    reads, off, seg, dropped = seqio.segments_from_files([fq, fa])
-    assert dropped == 1 and seg.tolist() == [0, 2, 4] and off.tolist() == [0, 6, 10, 16, 20]
-    assert reads.tobytes() == b"ACGTACTTTTACGTACGGGG"
+        f.write(b">c1\nACG\nTAC\n>c2\nGGGG\n\n>c3 multi\nAC\n\nGT\n")
+    crlf = tmp_path / "c.fq"
+    crlf.write_bytes(b"@x\r\nACGT\r\n+\r\nIIII\r\n@y\r\nGGCC\r\n+\r\nIIII")
+    empty = tmp_path / "d.fa"
+    empty.write_text("")
+    rng = np.random.default_rng(4)
+    big = tmp_path / "e.fastq.gz"
+    recs = ["".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(1, 200)))) for _ in range(3000)]
+    with gzip.open(big, "wb") as f:
+        f.write("".join(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" for i, r in enumerate(recs)).encode())
+    files = [fq, fa, crlf, empty, big]
+    words, off, seg, dropped = seqio.read_files(files)
+    reads, ooff, oseg, odropped = seq_oracle.segments_from_files(files)
+    assert dropped == odropped == 1
+    assert seg.tolist() == oseg.tolist() == [0, 2, 5, 7, 7, 3007]
+    assert off.tolist() == ooff.tolist()
+    mine = seqio.unpack_reads(words, off)
+    assert mine == [reads[int(ooff[i]):int(ooff[i + 1])].tobytes() for i in range(len(ooff) - 1)]
+    assert mine[:7] == [b"ACGTAC", b"TTTT", b"ACGTAC", b"GGGG", b"ACGT", b"ACGT", b"GGCC"] and mine[7:] == [r.encode() for r in recs]
+    with pytest.raises(ga.GasmError) as e:
+        seqio.read_files([fq], non_acgt="error")
+    assert "GASM_ERR_NON_ACGT" in str(e.value)
     with pytest.raises(ValueError):
-        seqio.segments_from_files([fq], non_acgt="error")
-    bad = tmp_path / "c.txt"
+        seq_oracle.segments_from_files([fq], non_acgt="error")
+    bad = tmp_path / "f.txt"
     bad.write_text("hello\n")
+    with pytest.raises(ga.GasmError):
+        seqio.read_files([bad])
     with pytest.raises(ValueError):
-        seqio.read_sequences(bad)
+        seq_oracle.read_sequences(bad)
+    with pytest.raises(ga.GasmError):
+        seqio.read_files([tmp_path / "does_not_exist.fq"])
 
 
 def test_assemble_short_contig_raises_like_reference():

@@ -321,17 +321,38 @@ def test_batch_from_fastq_files(tmp_path, qtable):
             with gzip.open(p, "wb") as f:
                 f.write("".join(f">r{i}\n{r[:30]}\n{r[30:]}\n" for i, r in enumerate(rs)).encode())
         paths.append(p)
+    from genomeassembler_dev_amd import seqio
+    from oracle import seq_oracle
     a = ga.SegmentBatch.from_fastq(paths)
-    b = ga.SegmentBatch.from_strings(segs)
-    assert a.dropped_reads == 1
+    assert a.dropped_reads == 1 and a.n_reads == sum(len(x) for x in segs)
     a.build(21).score(8, prob)
-    b.build(21).score(8, prob)
-    assert a.contigs() == b.contigs()
-    sa, sb = a.scores(), b.scores()
-    for kk in sa:
-        assert np.array_equal(np.nan_to_num(np.asarray(sa[kk])), np.nan_to_num(np.asarray(sb[kk]))), kk
+    # the checker: the oracle's own reading of the same files, then the oracle's graph and scores
+    o_reads, o_off, o_seg, o_dropped = seq_oracle.segments_from_files(paths)
+    assert o_dropped == 1
+    cs, sc = a.contigs(), a.scores()
+    for s in range(2):
+        rs = [o_reads[int(o_off[r]):int(o_off[r + 1])].tobytes().decode() for r in range(int(o_seg[s]), int(o_seg[s + 1]))]
+        assert rs == segs[s]
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, 21), 21, 1, rows=1)
+        assert cs[s] == ref["contigs"]
+        dk, dm = a.distinct_kmers(s)
+        assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist()
+        o = orc.calc_breakscore(cs[s], rs, "", 8, keys, prob, with_lev=False, with_freq=False)
+        ca, ce = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+        _check_scores({kk: v[ca:ce] for kk, v in sc.items() if kk != "seg_contig_off"}, o, with_lev=False)
     a.close()
+    # packed reads handed over directly (ragged and fixed length)
+    words, off, seg, _ = seqio.read_files(paths)
+    b = ga.SegmentBatch.from_packed(words, seg, read_off=off)
+    b.build(21)
+    assert b.contigs() == cs
     b.close()
+    b = ga.SegmentBatch.from_packed(words, seg, fixed_len=60)
+    b.build(21)
+    assert b.contigs() == cs
+    b.close()
+    with pytest.raises(ga.GasmError):
+        ga.SegmentBatch.from_fastq(paths, non_acgt="error")
 
 
 def test_batch_score_without_the_graph_shortcut(qtable):

@@ -1,0 +1,95 @@
+"""F4: KS statistic, coverage, solutions table (lib/DeNovoAssembler.R:318-479) — HIP path vs the oracle's restatement of
+R's ks.test / GRanges arithmetic.  The D statistic is also cross-checked against scipy.stats.ks_2samp (an independent
+implementation of the same textbook statistic; R itself is not available: its p-value is not restated)."""
+import numpy as np
+import pytest
+
+import genomeassembler_dev_amd as ga
+from genomeassembler_dev_amd import solutions, synth
+from oracle import orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _strs(a):
+    return [r.tobytes().decode() for r in a]
+
+
+def _case(seed, L=1500, rl=24, cov=40, k=15, rows=300):
+    g = synth.make_segment(seed, L, n_short=3, short_len=60, n_long=1, long_len=150, tandem_len=60, planted=True)
+    reads = _strs(synth.simulate_reads(g, rl, cov, seed + 1))
+    km = ga.get_kmers_from_reads(reads, k)
+    m = ga.get_contigs(km, k, 1234, matrix_rows=rows)
+    return g.tobytes().decode(), reads, ga.assemble_contigs(m, k)
+
+
+def test_ks_statistic_against_oracle_and_scipy(qtable):
+    from scipy import stats
+    keys, prob = qtable
+    for seed, table in ((41, prob), (42, ga.qtable.uniform())):
+        truth, reads, paths = _case(seed)
+        paths = paths + ["ACGTACGTACGTTTTT", truth[:40]]            # one path nothing matches (-> NaN), one short piece
+        m = ga.calc_breakscore(paths, reads, truth, 8, keys, table, with_lev=False, with_freq=True, with_ks=True)
+        o = orc.calc_breakscore(paths, reads, truth, 8, keys, table, with_lev=False, with_freq=True)
+        y = orc.kmer_from_seq(truth, 8, keys, table)
+        assert len(y) == len(truth) - 7
+        for i in range(len(paths)):
+            ref = orc.ks_statistic(o["path_freq"][i], y)
+            got = m["stat_test_KS"][i]
+            if np.isnan(ref):
+                assert np.isnan(got) and m["kmer_breaks"][i] == 0
+                continue
+            assert abs(got - ref) < 1e-9, (seed, i, got, ref)
+            assert abs(got - stats.ks_2samp(o["path_freq"][i], y).statistic) < 1e-9
+            # the HIP path's own path_freq (rows in bp_kmer order) gives the same statistic: only the multiset matters
+            assert abs(orc.ks_statistic(m["path_freq"][i], y) - ref) < 1e-12
+
+
+def test_coverage_percent_against_oracle():
+    rng = np.random.default_rng(9)
+    for L in (1, 37, 1000, 50000):
+        for n in (0, 1, 7, 300):
+            starts = rng.integers(-20, L + 30, n)
+            lens = rng.integers(0, max(2, L // 3), n)
+            assert ga.coverage_percent(starts, lens, L) == orc.coverage_percent(starts, lens, L), (L, n)
+    assert ga.coverage_percent([0], [10], 20) == 50.0           # [0, 10] covers 1..10 of 1..20
+
+
+def test_solutions_table_and_csv(tmp_path, qtable):
+    keys, prob = qtable
+    truth, reads, paths = _case(51, rows=200)
+    table = solutions.score_solutions(paths, reads, truth, 8)
+    assert tuple(table.keys()) == solutions.COLUMNS
+    # the oracle's restatement of the same lapply + join
+    y_t = orc.kmer_from_seq(truth, 8, keys, prob)
+    uni = ga.qtable.uniform()
+    y_u = orc.kmer_from_seq(truth, 8, keys, uni)
+    o_t = orc.calc_breakscore(paths, reads, truth, 8, keys, prob, with_lev=True, with_freq=True)
+    o_u = orc.calc_breakscore(paths, reads, truth, 8, keys, uni, with_lev=True, with_freq=True)
+    order = np.argsort(-o_t["bp_score"], kind="stable")
+    cov = orc.coverage_percent(np.zeros(len(paths), dtype=np.int64), o_t["sequence_len"], len(truth))
+    assert [paths[i] for i in order] == table["sequence"]
+    assert table["sequence_len"] == [int(o_t["sequence_len"][i]) for i in order]
+    assert table["kmer_breaks"] == [int(o_t["kmer_breaks"][i]) for i in order]
+    assert table["lev_dist_vs_true"] == [int(o_t["lev_dist_vs_true"][i]) for i in order]
+    assert all(c == cov for c in table["contig_frac_len"])
+    for r, i in enumerate(order):
+        assert abs(table["bp_score_true"][r] - o_t["bp_score"][i]) < 1e-9
+        assert abs(table["bp_score_random"][r] - o_u["bp_score"][i]) < 1e-9
+        assert abs(table["bp_score_norm_by_len_random"][r] - o_u["bp_score_norm_by_len"][i]) < 1e-9
+        for nm, oo, yy in (("stat_test_KS_true", o_t, y_t), ("stat_test_KS_random", o_u, y_u)):
+            ref = orc.ks_statistic(oo["path_freq"][i], yy)
+            assert (np.isnan(ref) and np.isnan(table[nm][r])) or abs(table[nm][r] - ref) < 1e-9
+    f = solutions.write_solutions_csv(tmp_path / solutions.solutions_filename(len(truth), 1234, 24, 15, 8), table)
+    lines = open(f).read().splitlines()
+    assert lines[0] == ("sequence,sequence_len,bp_score_true,bp_score_norm_by_break_freqs_true,bp_score_norm_by_len_true,kmer_breaks,"
+                        "lev_dist_vs_true,stat_test_KS_true,contig_frac_len,bp_score_random,bp_score_norm_by_break_freqs_random,"
+                        "bp_score_norm_by_len_random,stat_test_KS_random")
+    assert len(lines) == 1 + len(paths)
+    first = lines[1].split(",")
+    assert first[0] == table["sequence"][0] and int(first[1]) == len(table["sequence"][0])
+    assert abs(float(first[2]) - table["bp_score_true"][0]) < 1e-15 * max(1.0, abs(table["bp_score_true"][0]))
+    # the columns scripts/02_Real_vs_rand_prob_own.R:195-203 reads back are all there
+    for c in ("sequence_len", "kmer_breaks", "bp_score_norm_by_break_freqs_true", "bp_score_norm_by_len_true", "bp_score_true",
+              "lev_dist_vs_true", "stat_test_KS_true"):
+        assert c in lines[0].split(",")
