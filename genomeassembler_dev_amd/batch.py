@@ -62,6 +62,34 @@ class SegmentBatch:
         return self
 
     @classmethod
+    def simulate(cls, genomes, read_len, coverage, seed, kmer=8, table=None, ctx=None):
+        """reads simulated on the device from the segments' genomes (lib/GenerateReads.R:235-313, gasm_batch_simulate):
+        genomes = list of str/bytes/uint8 arrays; table = normalised 69 904-row table for probability-weighted starts
+        (the reference's ultrasonication model) or None for uniform starts"""
+        self = cls.__new__(cls)
+        self.ctx = ctx or default_context()
+        bs = [g.encode() if isinstance(g, str) else (g.tobytes() if hasattr(g, "tobytes") else bytes(g)) for g in genomes]
+        off = np.zeros(len(bs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        t = np.ascontiguousarray(table, dtype=np.float64) if table is not None else None
+        h = C.c_void_p()
+        check(lib().gasm_batch_simulate(self.ctx.h, b"".join(bs), off.ctypes.data_as(C.c_void_p), len(bs), int(read_len), float(coverage), int(seed),
+                                        int(kmer), t.ctypes.data_as(C.c_void_p) if t is not None else None, C.byref(h)))
+        self.h, self.k, self._table = h, None, None
+        self.n_segments = len(bs)
+        self.n_reads = int(lib().gasm_batch_total_reads(h))
+        return self
+
+    def read_starts(self):
+        """(seg_read_off[n_segments+1], 0-based start of every simulated read in its genome)"""
+        so, st = C.c_void_p(), C.c_void_p()
+        check(lib().gasm_batch_fetch_read_starts(self.h, C.byref(so), C.byref(st)))
+        seg = np.ctypeslib.as_array(C.cast(so, C.POINTER(C.c_uint64)), shape=(self.n_segments + 1,)).copy()
+        n = int(seg[-1])
+        starts = np.ctypeslib.as_array(C.cast(st, C.POINTER(C.c_uint32)), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        return seg, starts
+
+    @classmethod
     def from_fastq(cls, paths, non_acgt="drop", ctx=None):
         """one FASTQ/FASTA file (plain or .gz) per segment, read and packed by libgasm (gasm_batch_from_files); reads with a
         base outside ACGT are dropped (count in `.dropped_reads`) or, with non_acgt='error', refused"""

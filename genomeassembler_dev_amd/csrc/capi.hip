@@ -69,6 +69,10 @@ struct gasm_batch {
     std::vector<char> h_contigs;
     std::vector<double> h_bp, h_nf, h_nl;
     std::vector<int32_t> h_breaks, h_len;
+    // simulated batches: the start of every read in its genome
+    DBuf d_read_start;
+    std::vector<u32> h_read_start;
+    std::vector<u64> h_sim_seg_off;
 };
 
 // Read the report of a sub-batch's queued build (repeating the build if it failed, and then the scoring queued behind it).
@@ -463,8 +467,43 @@ int gasm_batch_from_files(gasm_ctx* ctx, const char* const* paths, uint32_t n_fi
     API_GUARD_END
 }
 
+int gasm_batch_simulate(gasm_ctx* ctx, const char* genomes, const uint64_t* genome_off, uint32_t n_segments, uint32_t read_len, double coverage,
+                        uint64_t seed, int kmer, const double* table, gasm_batch** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || !genomes || !genome_off) { gasm_set_error("gasm_batch_simulate: null argument"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    gasm_batch* b = new gasm_batch();
+    b->ctx = ctx;
+    b->n_segments = n_segments;
+    b->sub.resize(1);
+    SubBatch& sb = b->sub[0];
+    sb.cx = ctx; sb.seg0 = 0; sb.seg1 = n_segments;
+    const int st = sb.rd.simulate(ctx, genomes, genome_off, n_segments, read_len, coverage, seed, kmer, table, b->d_read_start);
+    if (st != GASM_OK) { gasm_batch_free(b); return st; }
+    b->n_reads = sb.rd.n_reads;
+    b->h_sim_seg_off = sb.rd.h_seg_read_off;
+    *out = b;
+    return GASM_OK;
+    API_GUARD_END
+}
+
+int gasm_batch_fetch_read_starts(gasm_batch* b, const uint64_t** seg_read_off, const uint32_t** starts) {
+    API_GUARD_BEGIN
+    if (!b || !seg_read_off || !starts) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
+    if (b->h_sim_seg_off.empty()) { gasm_set_error("not a simulated batch"); return GASM_ERR_STATE; }
+    b->h_read_start.resize(b->n_reads);
+    HIPCHK(hipSetDevice(b->ctx->device));
+    if (b->n_reads) HIPCHK(hipMemcpyAsync(b->h_read_start.data(), b->d_read_start.p, b->n_reads * 4, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIPCHK(hipStreamSynchronize(b->ctx->stream));
+    *seg_read_off = b->h_sim_seg_off.data();
+    *starts = b->h_read_start.data();
+    return GASM_OK;
+    API_GUARD_END
+}
+
 void gasm_batch_free(gasm_batch* b) {
     if (!b) return;
+    b->d_read_start.release();
     for (SubBatch& sb : b->sub) {
         if (sb.cx) { (void)hipSetDevice(sb.cx->device); (void)hipStreamSynchronize(sb.cx->stream); }
         sb.rd.release(); sb.bs.release(); sb.dp.release(); sb.tb.release(); sb.ss.release();

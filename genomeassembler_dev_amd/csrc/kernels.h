@@ -118,6 +118,13 @@ __global__ void k_bucket_merge(const K* in_keys, const u32* in_cnt, const u64* r
                                const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits);
 __global__ void k_repack_reads(const u64* src, const u64* dir, u64* words_out);
 
+// ---- kernels_sim.hip
+__global__ void k_sim_weights(const u64* gwords, const u64* gbase, const u64* woff, u32 n_segments, int kmer, const long long* fixw, u64* w);
+template <class T> __global__ void k_seg_scan_incl(T* a, const u64* off);
+__global__ void k_sim_draw(const u64* cum, const u64* woff, const u64* doff, const u64* glen, u64 seed, u32 read_len, u32* start, u32* keep);
+__global__ void k_sim_compact(const u32* start, const u32* keep, const u32* rank, const u64* doff, const u64* seg_read_off, u32* kept_start);
+__global__ void k_sim_extract(const u64* gwords, const u64* gbase, const u64* seg_read_off, const u32* kept_start, u32 read_len, unsigned long long* out);
+
 // ---- kernels_score.hip
 struct SeedTable {
     u64* seed;            // slot -> seed value

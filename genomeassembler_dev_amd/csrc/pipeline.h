@@ -25,6 +25,9 @@ struct DevReads {
                u32 n_segments);
     int upload_packed(gasm_ctx* ctx, const u64* words, const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off,
                       u32 n_segments);
+    // reads simulated on the device from the genomes (lib/GenerateReads.R:235-313); d_kept_start receives every read's start
+    int simulate(gasm_ctx* ctx, const char* genomes, const u64* genome_off, u32 n_segments, u32 read_len, double coverage, u64 seed, int kmer,
+                 const double* table, DBuf& d_kept_start);
     int set_layout(const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off, u32 n_segments);
     int finish_upload(gasm_ctx* ctx);
     int set_tiles(gasm_ctx* ctx, u32 ipt, u32 orr);

@@ -189,6 +189,90 @@ int DevReads::upload_packed(gasm_ctx* ctx, const u64* words, const u64* read_off
     return finish_upload(ctx);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Simulated reads, made on the device (kernels_sim.hip; lib/GenerateReads.R:235-313)
+// ---------------------------------------------------------------------------------------------------------------
+int DevReads::simulate(gasm_ctx* ctx, const char* genomes, const u64* genome_off, u32 S, u32 read_len, double coverage, u64 seed, int kmer,
+                       const double* table, DBuf& d_kept_start) {
+    if (!ctx || !genome_off || S == 0) { gasm_set_error("simulate: bad argument"); return GASM_ERR_INVALID; }
+    if (read_len == 0 || !(coverage >= 0.0) || kmer < 1 || kmer > 8) { gasm_set_error("simulate: read_len > 0, coverage >= 0, 1 <= kmer <= 8"); return GASM_ERR_INVALID; }
+    HIPCHK(hipSetDevice(ctx->device));
+    std::vector<u64> gbase((size_t)S + 1), glen(S), woff((size_t)S + 1, 0), doff((size_t)S + 1, 0);
+    u64 max_np = 0, max_nd = 0;
+    for (u32 s = 0; s <= S; ++s) {
+        if (s && genome_off[s] < genome_off[s - 1]) { gasm_set_error("genome_off not monotone"); return GASM_ERR_INVALID; }
+        gbase[s] = genome_off[s] - genome_off[0];
+    }
+    for (u32 s = 0; s < S; ++s) {
+        const u64 L = gbase[s + 1] - gbase[s];
+        if (L > 0xFFFFFFF0ull) { gasm_set_error("genome longer than 2^32"); return GASM_ERR_CAPACITY; }
+        glen[s] = L;
+        const u64 np = L >= (u64)kmer ? L - kmer + 1 : 0;                                // lib/GenerateReads.R:243
+        const u64 nd = np ? (u64)std::ceil(coverage * (double)L / (double)read_len) : 0;   // :302
+        woff[s + 1] = woff[s] + np;
+        doff[s + 1] = doff[s] + nd;
+        max_np = std::max(max_np, np); max_nd = std::max(max_nd, nd);
+    }
+    DBuf ascii, err, gwords, d_gbase, d_glen, d_woff, d_doff, d_w, d_fix, d_start, d_keep, d_rank, d_sro;
+    struct Rel { std::vector<DBuf*> v; ~Rel() { for (DBuf* b : v) b->release(); } } rel{{&ascii, &err, &gwords, &d_gbase, &d_glen, &d_woff, &d_doff, &d_w, &d_fix,
+                                                                                         &d_start, &d_keep, &d_rank, &d_sro}};
+    GCHK(err.ensure(8));
+    HIPCHK(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+    GCHK(h2d(ctx, ascii, genomes + genome_off[0], gbase[S]));
+    GCHK(pack_ascii(ctx, ascii.as<u8>(), gbase[S], gwords, err.as<u32>()));
+    GCHK(h2d(ctx, d_gbase, gbase.data(), gbase.size() * 8));
+    GCHK(h2d(ctx, d_glen, glen.data(), glen.size() * 8));
+    GCHK(h2d(ctx, d_woff, woff.data(), woff.size() * 8));
+    GCHK(h2d(ctx, d_doff, doff.data(), doff.size() * 8));
+    const long long* fixw = nullptr;
+    if (table) {
+        // the kmer-long rows of the standard table (rows of lengths 2, 4, 6, 8 in that order), direct-addressed, in fixed point
+        if (kmer != 2 && kmer != 4 && kmer != 6 && kmer != 8) { gasm_set_error("the weighted simulator needs kmer in {2,4,6,8} (the table's row lengths)"); return GASM_ERR_INVALID; }
+        std::vector<long long> fx(87380, 0);
+        u32 src = 0;
+        for (u32 Lk = 2; Lk <= 8; Lk += 2) {
+            const u32 n = 1u << (2 * Lk), b = ((1u << (2 * Lk)) - 4u) / 3u;
+            for (u32 v = 0; v < n; ++v, ++src) if ((int)Lk == kmer) fx[b + v] = std::llrint(std::ldexp(table[src], 52));
+        }
+        GCHK(h2d(ctx, d_fix, fx.data(), fx.size() * 8));
+        fixw = d_fix.as<long long>();
+    }
+    GCHK(d_w.ensure(std::max<u64>(woff[S], 1) * 8));
+    GCHK(d_start.ensure(std::max<u64>(doff[S], 1) * 4));
+    GCHK(d_keep.ensure(std::max<u64>(doff[S], 1) * 4));
+    GCHK(d_rank.ensure(std::max<u64>(doff[S], 1) * 4));
+    const u32 gx_p = std::max(1u, std::min<u32>(ceil_div_u64(std::max<u64>(max_np, 1), GASM_WG), 64u));
+    const u32 gx_d = std::max(1u, std::min<u32>(ceil_div_u64(std::max<u64>(max_nd, 1), GASM_WG), 64u));
+    GLAUNCH(ctx, "k_sim_weights", k_sim_weights, dim3(gx_p, S), dim3(GASM_WG), 0, gwords.as<u64>(), d_gbase.as<u64>(), d_woff.as<u64>(), S, kmer, fixw, d_w.as<u64>());
+    GLAUNCH(ctx, "k_seg_scan_incl", k_seg_scan_incl<u64>, dim3(S), dim3(1024), 0, d_w.as<u64>(), d_woff.as<u64>());
+    GLAUNCH(ctx, "k_sim_draw", k_sim_draw, dim3(gx_d, S), dim3(GASM_WG), 0, d_w.as<u64>(), d_woff.as<u64>(), d_doff.as<u64>(), d_glen.as<u64>(), seed, read_len,
+            d_start.as<u32>(), d_keep.as<u32>());
+    if (doff[S]) HIPCHK(hipMemcpyAsync(d_rank.p, d_keep.p, doff[S] * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    GLAUNCH(ctx, "k_seg_scan_incl", k_seg_scan_incl<u32>, dim3(S), dim3(1024), 0, d_rank.as<u32>(), d_doff.as<u64>());
+    // kept reads per segment = the last rank of the segment
+    std::vector<u32> last(S, 0);
+    u32 herr = 0;
+    HIPCHK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    for (u32 s = 0; s < S; ++s)
+        if (doff[s + 1] > doff[s]) HIPCHK(hipMemcpyAsync(&last[s], d_rank.as<u32>() + doff[s + 1] - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (herr) { gasm_set_error("a genome holds a base outside upper-case ACGT"); return GASM_ERR_NON_ACGT; }
+    std::vector<u64> sro((size_t)S + 1, 0);
+    for (u32 s = 0; s < S; ++s) sro[s + 1] = sro[s] + last[s];
+    const u64 n = sro[S];
+    GCHK(set_layout(nullptr, n, read_len, sro.data(), S));
+    GCHK(h2d(ctx, d_sro, sro.data(), sro.size() * 8));
+    GCHK(d_kept_start.ensure(std::max<u64>(n, 1) * 4));
+    GLAUNCH(ctx, "k_sim_compact", k_sim_compact, dim3(gx_d, S), dim3(GASM_WG), 0, d_start.as<u32>(), d_keep.as<u32>(), d_rank.as<u32>(), d_doff.as<u64>(), d_sro.as<u64>(),
+            d_kept_start.as<u32>());
+    const u64 nw = (total_bases + 31) / 32;
+    GCHK(d_words.ensure((nw + 4) * 8));
+    HIPCHK(hipMemsetAsync(d_words.p, 0, (nw + 4) * 8, ctx->stream));
+    if (n) GLAUNCH(ctx, "k_sim_extract", k_sim_extract, dim3(std::max(1u, std::min<u32>(ceil_div_u64(max_nd * ((read_len + 31) / 32), GASM_WG), 256u)), S), dim3(GASM_WG), 0,
+                   gwords.as<u64>(), d_gbase.as<u64>(), d_sro.as<u64>(), d_kept_start.as<u32>(), read_len, d_words.as<unsigned long long>());
+    return finish_upload(ctx);
+}
+
 // Tile table: a tile = up to ipt consecutive reads of one segment at one of orr offset rounds (kernels_build.hip, "Tiles").
 int DevReads::set_tiles(gasm_ctx* ctx, u32 ipt, u32 orr) {
     if (tiles_ipt == ipt && tiles_orr == orr) return GASM_OK;

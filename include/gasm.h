@@ -178,6 +178,16 @@ int gasm_batch_create_packed(gasm_ctx* ctx, const uint64_t* words, const uint64_
  * counted in *dropped_reads, 1 = GASM_ERR_NON_ACGT.  The host packs 2-bit while it parses. */
 int gasm_batch_from_files(gasm_ctx* ctx, const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_batch** out,
                           uint64_t* dropped_reads);
+/* Simulated reads, made on the device (lib/GenerateReads.R:235-313): per segment ceil(coverage * L / read_len) start
+ * positions drawn with replacement, the weight of a position = table probability of the kmer-long window starting there
+ * (table = the GASM_TABLE_ROWS normalised probabilities, kmer in {2,4,6,8}; table = NULL: every one of the L - kmer + 1
+ * positions weighs the same), starts whose read would run past the end dropped, reads = substrings of the genome, forward
+ * strand.  R's sample()/set.seed stream is not reproducible without R; the draws here are a documented counter-based
+ * generator (kernels_sim.hip), identical for the same (seed, genomes) and restated by the oracle.
+ * gasm_batch_fetch_read_starts: the 0-based start of every read in its genome (n_segments + 1 offsets, n_reads starts). */
+int gasm_batch_simulate(gasm_ctx* ctx, const char* genomes, const uint64_t* genome_off, uint32_t n_segments, uint32_t read_len,
+                        double coverage, uint64_t seed, int kmer, const double* table, gasm_batch** out);
+int gasm_batch_fetch_read_starts(gasm_batch* b, const uint64_t** seg_read_off, const uint32_t** starts);
 /* the reader alone (host only, no GPU needed): the reads of the files, packed as gasm_batch_create_packed takes them */
 typedef struct gasm_packed gasm_packed;
 int gasm_read_files(const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_packed** out);

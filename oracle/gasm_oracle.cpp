@@ -642,4 +642,50 @@ double orc_coverage_percent(const int64_t* start, const int64_t* len, uint64_t n
     return (1.0 - (double)unc / (double)seq_len) * 100.0;
 }
 
+// ---------------------------------------------------------------------------
+// F3 — the read simulator (lib/GenerateReads.R:235-313), restated with the build's own pinned random stream (R's
+// sample() cannot be reproduced without R): n = ceil(coverage * L / read_len) draws (:302) with replacement over the
+// L - kmer + 1 start positions, weight = probability of the kmer-long window starting there (:243-259, :303-308; nullptr:
+// equal weights), draws whose read would run past the end dropped (:310-313), kept starts in draw order.
+// Integer procedure (the HIP path does the same arithmetic, kernels_sim.hip): weight = llrint(prob * 2^52), running sums in
+// u64, draw d of segment s = mix64(mix64(seed ^ (0xD1B54A32D192ED03 * (s + 1))) + d) with splitmix64's output function,
+// r = high 64 bits of draw * total, start = first position whose running sum exceeds r.
+// ---------------------------------------------------------------------------
+static inline uint64_t sim_mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+uint64_t orc_simulate_starts(const char* genome, uint64_t L, uint32_t seg_index, uint32_t read_len, double coverage, uint64_t seed,
+                             int kmer, const char* kd, const uint64_t* koff, uint64_t nk, const double* prob, uint32_t* out_starts) {
+    if (L < (uint64_t)kmer) return 0;
+    const uint64_t np_ = L - kmer + 1;
+    std::vector<uint64_t> cum(np_);
+    std::unordered_map<std::string, double> t;
+    if (prob) {
+        orc::StrVec keys = unpack(kd, koff, nk);
+        for (uint64_t i = 0; i < nk; ++i) if ((int)keys[i].size() == kmer) t.emplace(keys[i], prob[i]);
+    }
+    const std::string g(genome, L);
+    uint64_t run = 0;
+    for (uint64_t p = 0; p < np_; ++p) {
+        uint64_t w = 1;
+        if (prob) w = (uint64_t)std::llrint(std::ldexp(t.at(g.substr(p, kmer)), 52));
+        run += w;
+        cum[p] = run;
+    }
+    const uint64_t nd = (uint64_t)std::ceil(coverage * (double)L / (double)read_len);
+    const uint64_t sseed = sim_mix64(seed ^ (0xD1B54A32D192ED03ull * (uint64_t)(seg_index + 1)));
+    uint64_t kept = 0;
+    if (run == 0) return 0;
+    for (uint64_t d = 0; d < nd; ++d) {
+        const uint64_t x = sim_mix64(sseed + d);
+        const uint64_t r = (uint64_t)(((unsigned __int128)x * run) >> 64);
+        const uint64_t p = (uint64_t)(std::upper_bound(cum.begin(), cum.end(), r) - cum.begin());
+        if (p + read_len <= L) out_starts[kept++] = (uint32_t)p;
+    }
+    return kept;
+}
+
 }  // extern "C"

@@ -249,3 +249,21 @@ def coverage_percent(starts, lens, seq_len):
     f = lib().orc_coverage_percent
     f.restype = C.c_double
     return f(_p(a), _p(b), C.c_uint64(len(a)), C.c_int64(seq_len))
+
+
+def simulate_starts(genome, seg_index, read_len, coverage, seed, kmer=8, bp_kmer=None, bp_prob=None):
+    """lib/GenerateReads.R:235-313 with the build's pinned random stream: kept 0-based read starts, in draw order"""
+    g = genome.encode() if isinstance(genome, str) else bytes(genome)
+    nd = int(np.ceil(coverage * len(g) / read_len)) + 1
+    out = np.zeros(nd, dtype=np.uint32)
+    f = lib().orc_simulate_starts
+    f.restype = C.c_uint64
+    if bp_prob is not None:
+        kb, ko = _pack(bp_kmer)
+        prob = np.ascontiguousarray(bp_prob, dtype=np.float64)
+        n = f(g, C.c_uint64(len(g)), C.c_uint32(seg_index), C.c_uint32(read_len), C.c_double(coverage), C.c_uint64(seed), C.c_int(kmer), kb, _p(ko),
+              C.c_uint64(len(bp_kmer)), _p(prob), _p(out))
+    else:
+        n = f(g, C.c_uint64(len(g)), C.c_uint32(seg_index), C.c_uint32(read_len), C.c_double(coverage), C.c_uint64(seed), C.c_int(kmer), None, None,
+              C.c_uint64(0), None, _p(out))
+    return out[:int(n)].copy()

@@ -611,3 +611,45 @@ def test_sub_batches_on_lanes(qtable, monkeypatch):
         a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
         _check_scores({kk: v[a:e] for kk, v in sc.items() if kk != "seg_contig_off"}, o, with_lev=False)
     b.close()
+
+
+def test_read_simulator_against_oracle(qtable):
+    """gasm_batch_simulate (reads made on the device: weights -> scan -> draws -> kept starts -> packed reads) against the
+    oracle's restatement of lib/GenerateReads.R:235-313 with the same pinned random stream: the kept starts bit-exact, per
+    segment, weighted (the reference's ultrasonication model) and uniform; then the batch built from those reads equals
+    the batch built from the same reads handed over as text.  Statistical sanity: weighted starts follow the weights."""
+    keys, prob = qtable
+    genomes = [synth.make_segment(9000 + s, L, planted=True) for s, L in enumerate((6000, 2500, 9, 4000, 7))]
+    gs = [g.tobytes().decode() for g in genomes]
+    for table, rl, cov, seed in ((prob, 40, 12.0, 5), (None, 75, 7.5, 2**40 + 3), (ga.qtable.uniform(), 33, 3.0, 0)):
+        b = ga.SegmentBatch.simulate(gs, rl, cov, seed, kmer=8, table=table)
+        seg, starts = b.read_starts()
+        all_reads = []
+        for s, g in enumerate(gs):
+            ref = orc.simulate_starts(g, s, rl, cov, seed, 8, keys if table is not None else None, table)
+            assert starts[int(seg[s]):int(seg[s + 1])].tolist() == ref.tolist(), (s, rl)
+            assert all(int(p) + rl <= len(g) for p in ref)
+            all_reads.append([g[int(p):int(p) + rl] for p in ref])
+        assert len(all_reads[2]) == 0 and len(all_reads[4]) == 0          # genomes shorter than a read
+        k = 17
+        b.build(k)
+        t = ga.SegmentBatch.from_strings(all_reads)
+        t.build(k)
+        assert b.contigs() == t.contigs()
+        for s in (0, 1, 3):
+            ref = orc.get_contigs(orc.kmers_from_reads(all_reads[s], k), k, 1, rows=1)
+            assert b.contigs(s) == ref["contigs"]
+            dk, dm = b.distinct_kmers(s)
+            assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist()
+        b.close()
+        t.close()
+    # weights steer the draws: two 8-mers with very different probabilities, counted over many draws
+    g = gs[0]
+    b = ga.SegmentBatch.simulate([g], 20, 400.0, 11, kmer=8, table=prob)
+    _, starts = b.read_starts()
+    y = orc.kmer_from_seq(g, 8, keys, prob)
+    hi, lo = int(np.argmax(y[:5000])), int(np.argmin(y[:5000]))
+    cnt = np.bincount(starts, minlength=len(g))
+    expect_ratio = y[hi] / y[lo]
+    assert cnt[hi] > cnt[lo] and 0.5 * expect_ratio < (cnt[hi] + 1) / (cnt[lo] + 1) < 2.0 * expect_ratio
+    b.close()
