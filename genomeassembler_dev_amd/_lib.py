@@ -44,6 +44,13 @@ SYMBOLS = {
     "gasm_contigs_free": (None, [_vp]),
     "gasm_assemble_contigs": (_int, [_vp, _vp, _vp, _u64, _vp, _u64, _u64, _int, _PP]),
     "gasm_assemble_contigs_velvet": (_int, [_vp, _vp, _vp, _u64, _int, _int, _int, _PP]),
+    "gasm_assemble_contigs_dev": (_int, [_vp, _vp, _vp, _u64, _vp, _u64, _u64, _int, _PP]),
+    "gasm_assemble_contigs_velvet_dev": (_int, [_vp, _vp, _vp, _u64, _int, _int, _int, _PP]),
+    "gasm_scaffolds_count": (_u64, [_vp]),
+    "gasm_scaffolds_offsets": (_vp, [_vp]),
+    "gasm_scaffolds_fetch": (_int, [_vp, _PP]),
+    "gasm_scaffolds_free": (None, [_vp]),
+    "gasm_calc_breakscore_dev": (_int, [_vp, _vp, _vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _u64, _vp, _int, _int, _PP]),
     "gasm_strlist_count": (_u64, [_vp]),
     "gasm_strlist_data": (_vp, [_vp]),
     "gasm_strlist_offsets": (_vp, [_vp]),

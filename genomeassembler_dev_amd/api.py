@@ -132,8 +132,39 @@ def _raise(e):
     raise e
 
 
-def assemble_contigs(contig_matrix, dbg_kmer, ctx=None):
-    """contig_matrix: a ContigMatrix, or the reference's list of equally long lists of strings."""
+class Scaffolds:
+    """Distinct scaffolds of assemble_contigs left on the GPU (2-bit, the reference's order: longest first).  Pass it to
+    calc_breakscore as `path`; `.strings()` makes the text."""
+
+    def __init__(self, h, ctx):
+        self.h, self.ctx = h, ctx
+        n = lib().gasm_scaffolds_count(h)
+        off = _arr(lib().gasm_scaffolds_offsets(h), C.c_uint64, n + 1)
+        self.lengths = np.diff(off).astype(np.int64) if n else np.zeros(0, np.int64)
+
+    def __len__(self):
+        return len(self.lengths)
+
+    def strings(self):
+        h = C.c_void_p()
+        check(lib().gasm_scaffolds_fetch(self.h, C.byref(h)))
+        return _strlist(h)
+
+    def close(self):
+        if self.h:
+            lib().gasm_scaffolds_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def assemble_contigs(contig_matrix, dbg_kmer, ctx=None, on_device=False):
+    """contig_matrix: a ContigMatrix, or the reference's list of equally long lists of strings.
+    on_device=True: returns a `Scaffolds` handle (nothing is copied back) instead of the list of strings."""
     if isinstance(contig_matrix, ContigMatrix):
         contigs, perm = contig_matrix.contigs, contig_matrix.perm
     else:
@@ -148,6 +179,11 @@ def assemble_contigs(contig_matrix, dbg_kmer, ctx=None):
     perm = np.ascontiguousarray(perm, dtype=np.uint32)
     h = C.c_void_p()
     try:
+        if on_device:
+            ctx = ctx or default_context()
+            check(lib().gasm_assemble_contigs_dev(ctx.h, buf, _ptr(off), len(contigs), _ptr(perm), perm.shape[0], perm.shape[1], int(dbg_kmer),
+                                                  C.byref(h)))
+            return Scaffolds(h, ctx)
         check(lib().gasm_assemble_contigs(ctx.h if ctx else None, buf, _ptr(off), len(contigs), _ptr(perm), perm.shape[0],
                                           perm.shape[1], int(dbg_kmer), C.byref(h)))
     except GasmError as e:
@@ -155,10 +191,14 @@ def assemble_contigs(contig_matrix, dbg_kmer, ctx=None):
     return _strlist(h)
 
 
-def assemble_contigs_velvet(velvet_contigs, dbg_kmer, seed, rows=20000, ctx=None):
+def assemble_contigs_velvet(velvet_contigs, dbg_kmer, seed, rows=20000, ctx=None, on_device=False):
     buf, off = _pack(velvet_contigs)
     h = C.c_void_p()
     try:
+        if on_device:
+            ctx = ctx or default_context()
+            check(lib().gasm_assemble_contigs_velvet_dev(ctx.h, buf, _ptr(off), len(velvet_contigs), int(dbg_kmer), int(seed), int(rows), C.byref(h)))
+            return Scaffolds(h, ctx)
         check(lib().gasm_assemble_contigs_velvet(ctx.h if ctx else None, buf, _ptr(off), len(velvet_contigs), int(dbg_kmer),
                                                  int(seed), int(rows), C.byref(h)))
     except GasmError as e:
@@ -183,20 +223,25 @@ def calc_breakscore(path, sequencing_reads, true_solution, kmer, bp_kmer, bp_pro
     velvet = variant == "velvet"
     if variant not in ("own", "velvet"):
         raise ValueError("variant must be 'own' or 'velvet'")
-    pb, po = _pack(path)
     rb, ro = _pack(sequencing_reads)
     kb, ko = _pack(bp_kmer)
     prob = np.ascontiguousarray(bp_prob, dtype=np.float64)
     t = true_solution.encode() if isinstance(true_solution, str) else bytes(true_solution)
     flags = (_lib.WANT_LEV if with_lev else 0) | (_lib.WANT_FREQ if with_freq and not velvet else 0) | (_lib.WANT_KS if with_ks else 0)
     h = C.c_void_p()
-    check(lib().gasm_calc_breakscore(ctx.h, pb, _ptr(po), len(path), rb, _ptr(ro), len(sequencing_reads), t, len(t), int(kmer),
-                                     kb, _ptr(ko), len(bp_kmer), _ptr(prob), _lib.SCORE_VELVET if velvet else _lib.SCORE_OWN,
-                                     flags, C.byref(h)))
+    if isinstance(path, Scaffolds):
+        # the scaffolds are on the device already (assemble_contigs(..., on_device=True)): no text, no upload
+        check(lib().gasm_calc_breakscore_dev(ctx.h, path.h, rb, _ptr(ro), len(sequencing_reads), t, len(t), int(kmer), kb, _ptr(ko), len(bp_kmer),
+                                             _ptr(prob), _lib.SCORE_VELVET if velvet else _lib.SCORE_OWN, flags, C.byref(h)))
+    else:
+        pb, po = _pack(path)
+        check(lib().gasm_calc_breakscore(ctx.h, pb, _ptr(po), len(path), rb, _ptr(ro), len(sequencing_reads), t, len(t), int(kmer),
+                                         kb, _ptr(ko), len(bp_kmer), _ptr(prob), _lib.SCORE_VELVET if velvet else _lib.SCORE_OWN,
+                                         flags, C.byref(h)))
     L = lib()
     try:
         n = L.gasm_scores_count(h)
-        out = dict(sequence=list(path),
+        out = dict(sequence=(path if isinstance(path, Scaffolds) else list(path)),
                    sequence_len=_arr(L.gasm_scores_sequence_len(h), C.c_int32, n),
                    bp_score=_arr(L.gasm_scores_bp_score(h), C.c_double, n),
                    bp_score_norm_by_break_freqs=_arr(L.gasm_scores_norm_by_break_freqs(h), C.c_double, n),

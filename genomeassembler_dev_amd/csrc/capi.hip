@@ -1,10 +1,13 @@
 // capi.hip — the extern "C" surface declared in include/gasm.h.
 #include <algorithm>
 #include <atomic>
+#include <functional>
+#include <mutex>
 #include <new>
 #include <thread>
 
 #include "pipeline.h"
+#include "scaffolds.h"
 
 struct gasm_strlist {
     std::vector<char> data;
@@ -115,6 +118,11 @@ static void strlist_from(const std::vector<std::string>& v, std::vector<char>& d
 
 extern "C" {
 
+static int breakscore_impl(gasm_ctx* ctx, DevPaths& dp, const std::function<std::string(u64)>& path_text, uint64_t n_paths, const char* reads,
+                           const uint64_t* read_off, uint64_t n_reads, const char* true_solution, uint64_t true_len, int kmer,
+                           const char* bp_kmer, const uint64_t* bp_off, uint64_t n_table, const double* bp_prob, int variant,
+                           int flags, gasm_scores** out);
+
 // ------------------------------------------------------------------------------------------------- get_contigs
 int gasm_get_contigs(gasm_ctx* ctx, const char* kmers, uint64_t n_kmers, int dbg_kmer, int seed, int matrix_rows,
                      gasm_contigs** out) {
@@ -162,7 +170,36 @@ const uint32_t* gasm_contigs_distinct_mult(const gasm_contigs* c) { return c ? c
 void gasm_contigs_free(gasm_contigs* c) { delete c; }
 
 // -------------------------------------------------------------------------------------------- assemble_contigs
-static int assemble_common(const char* contigs, const u64* off, u64 n, const u32* perm, u64 rows, u64 row_len, int k, gasm_strlist** out) {
+// the device route: greedy merge on contig indices (host threads), scaffolds expanded, ordered and de-duplicated on the GPU
+// *used = false when the index form does not apply (the caller takes the host's string form)
+static int assemble_device(gasm_ctx* ctx, const char* contigs, const u64* off, u64 n, const u32* perm, u64 rows, u64 row_len, int k, gasm_scaffolds** out,
+                           bool* used) {
+    *used = false;
+    std::vector<std::string> c(n);
+    for (u64 i = 0; i < n; ++i) c[i].assign(contigs + off[i], contigs + off[i + 1]);
+    for (u64 i = 0; i < rows * row_len; ++i)
+        if (perm[i] >= n) { gasm_set_error("perm[%llu] = %u out of range", (unsigned long long)i, perm[i]); return GASM_ERR_INVALID; }
+    if (row_len != n) return GASM_OK;                       // (rows that are not permutations of all contigs: the string form)
+    std::vector<std::string> sigs;
+    if (!gasm_host::assemble_signatures(c, perm, rows, row_len, k, sigs)) return GASM_OK;
+    *used = true;
+    return scaffolds_from_signatures(ctx, c, sigs, out);
+}
+
+static int assemble_common(gasm_ctx* ctx, const char* contigs, const u64* off, u64 n, const u32* perm, u64 rows, u64 row_len, int k, gasm_strlist** out) {
+    if (ctx && !getenv("GASM_ASM_HOST")) {
+        gasm_scaffolds* sc = nullptr;
+        bool used = false;
+        GCHK(assemble_device(ctx, contigs, off, n, perm, rows, row_len, k, &sc, &used));
+        if (used) {
+            gasm_strlist* s = new gasm_strlist();
+            const int st = scaffolds_fetch(sc, s->data, s->off);
+            gasm_scaffolds_free(sc);
+            if (st != GASM_OK) { delete s; return st; }
+            *out = s;
+            return GASM_OK;
+        }
+    }
     std::vector<std::string> c(n);
     for (u64 i = 0; i < n; ++i) c[i].assign(contigs + off[i], contigs + off[i + 1]);
     for (u64 i = 0; i < rows * row_len; ++i)
@@ -178,22 +215,113 @@ static int assemble_common(const char* contigs, const u64* off, u64 n, const u32
 int gasm_assemble_contigs(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, const uint32_t* perm,
                           uint64_t rows, uint64_t row_len, int dbg_kmer, gasm_strlist** out) {
     API_GUARD_BEGIN
-    (void)ctx;  // host algorithm in this version
     if (!out || !off || (n && !contigs) || (rows && row_len && !perm)) { gasm_set_error("gasm_assemble_contigs: null argument"); return GASM_ERR_INVALID; }
     *out = nullptr;
-    return assemble_common(contigs, off, n, perm, rows, row_len, dbg_kmer, out);
+    return assemble_common(ctx, contigs, off, n, perm, rows, row_len, dbg_kmer, out);
     API_GUARD_END
 }
 
 int gasm_assemble_contigs_velvet(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, int dbg_kmer, int seed,
                                  int rows, gasm_strlist** out) {
     API_GUARD_BEGIN
-    (void)ctx;
     if (!out || !off || (n && !contigs) || rows < 0) { gasm_set_error("gasm_assemble_contigs_velvet: bad argument"); return GASM_ERR_INVALID; }
     *out = nullptr;
     std::vector<u32> perm;
     gasm_host::shuffle_perm(n, seed, (u64)rows, perm);  // lib/BreakageScorer.cpp:86-94
-    return assemble_common(contigs, off, n, perm.data(), (u64)rows, n, dbg_kmer, out);
+    return assemble_common(ctx, contigs, off, n, perm.data(), (u64)rows, n, dbg_kmer, out);
+    API_GUARD_END
+}
+
+// ---- the same with the scaffolds left on the device
+int gasm_assemble_contigs_dev(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, const uint32_t* perm, uint64_t rows, uint64_t row_len,
+                              int dbg_kmer, gasm_scaffolds** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || !off || (n && !contigs) || (rows && row_len && !perm)) { gasm_set_error("gasm_assemble_contigs_dev: null argument"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    bool used = false;
+    GCHK(assemble_device(ctx, contigs, off, n, perm, rows, row_len, dbg_kmer, out, &used));
+    if (!used) {
+        // contigs shorter than k-1 (the reference compares whole strings or throws there), or rows that are not full
+        // permutations: the host's string form, then the text goes to the device as a one-contig-per-scaffold chain set
+        gasm_strlist* sl = nullptr;
+        GCHK(assemble_common(nullptr, contigs, off, n, perm, rows, row_len, dbg_kmer, &sl));
+        std::vector<std::string> txt(sl->off.size() - 1), sigs;
+        for (size_t i = 0; i + 1 < sl->off.size(); ++i) txt[i].assign(sl->data.data() + sl->off[i], sl->data.data() + sl->off[i + 1]);
+        gasm_strlist_free(sl);
+        // (already sorted, distinct and in final order: hand them over as they are)
+        gasm_scaffolds* sc = new gasm_scaffolds();
+        sc->ctx = ctx; sc->n = (u32)txt.size();
+        sc->h_off.assign(1, 0);
+        std::string cat;
+        for (auto& t : txt) { cat += t; sc->h_off.push_back(cat.size()); }
+        DevPaths tmp;
+        std::vector<u64> o(sc->h_off);
+        const int st = tmp.upload_ascii(ctx, cat.data(), o.data(), sc->n);
+        if (st != GASM_OK) { tmp.release(); delete sc; return st; }
+        sc->d_words = tmp.d_words; tmp.d_words = DBuf();
+        tmp.release();
+        *out = sc;
+    }
+    return GASM_OK;
+    API_GUARD_END
+}
+
+int gasm_assemble_contigs_velvet_dev(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, int dbg_kmer, int seed, int rows,
+                                     gasm_scaffolds** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || !off || (n && !contigs) || rows < 0) { gasm_set_error("gasm_assemble_contigs_velvet_dev: bad argument"); return GASM_ERR_INVALID; }
+    std::vector<u32> perm;
+    gasm_host::shuffle_perm(n, seed, (u64)rows, perm);  // lib/BreakageScorer.cpp:86-94
+    return gasm_assemble_contigs_dev(ctx, contigs, off, n, perm.data(), (u64)rows, n, dbg_kmer, out);
+    API_GUARD_END
+}
+
+uint64_t gasm_scaffolds_count(const gasm_scaffolds* s) { return s ? s->n : 0; }
+const uint64_t* gasm_scaffolds_offsets(const gasm_scaffolds* s) { return s ? s->h_off.data() : nullptr; }
+int gasm_scaffolds_fetch(const gasm_scaffolds* s, gasm_strlist** out) {
+    API_GUARD_BEGIN
+    if (!s || !out) { gasm_set_error("gasm_scaffolds_fetch: null argument"); return GASM_ERR_INVALID; }
+    gasm_strlist* l = new gasm_strlist();
+    const int st = scaffolds_fetch(s, l->data, l->off);
+    if (st != GASM_OK) { delete l; return st; }
+    *out = l;
+    return GASM_OK;
+    API_GUARD_END
+}
+void gasm_scaffolds_free(gasm_scaffolds* s) {
+    if (!s) return;
+    if (s->ctx) { (void)hipSetDevice(s->ctx->device); (void)hipStreamSynchronize(s->ctx->stream); }
+    s->d_words.release();
+    delete s;
+}
+
+int gasm_calc_breakscore_dev(gasm_ctx* ctx, const gasm_scaffolds* paths, const char* reads, const uint64_t* read_off, uint64_t n_reads,
+                             const char* true_solution, uint64_t true_len, int kmer, const char* bp_kmer, const uint64_t* bp_off, uint64_t n_table,
+                             const double* bp_prob, int variant, int flags, gasm_scores** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || !paths || !read_off || !bp_off || (n_table && (!bp_kmer || !bp_prob)) || (true_len && !true_solution)) {
+        gasm_set_error("gasm_calc_breakscore_dev: null argument");
+        return GASM_ERR_INVALID;
+    }
+    if (variant != GASM_SCORE_OWN && variant != GASM_SCORE_VELVET) { gasm_set_error("unknown variant %d", variant); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    DevPaths dp;
+    int st = scaffolds_as_paths(paths, dp);
+    // text of single paths is rarely needed (velvet startpos, host Levenshtein): fetched once, on first use
+    std::vector<char> txt;
+    std::vector<u64> toff;
+    std::mutex mu;
+    bool have = false;
+    auto path_text = [&](u64 p) {
+        std::lock_guard<std::mutex> g(mu);
+        if (!have) { (void)scaffolds_fetch(paths, txt, toff); have = true; }
+        return toff.size() > p + 1 ? std::string(txt.data() + toff[p], txt.data() + toff[p + 1]) : std::string();
+    };
+    if (st == GASM_OK)
+        st = breakscore_impl(ctx, dp, path_text, paths->n, reads, read_off, n_reads, true_solution, true_len, kmer, bp_kmer, bp_off, n_table, bp_prob,
+                             variant, flags, out);
+    dp.release();
+    return st;
     API_GUARD_END
 }
 
@@ -211,27 +339,20 @@ int gasm_levenshtein(const char* query, uint64_t nq, const char* target, uint64_
     API_GUARD_END
 }
 
-int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_off, uint64_t n_paths, const char* reads,
-                         const uint64_t* read_off, uint64_t n_reads, const char* true_solution, uint64_t true_len, int kmer,
-                         const char* bp_kmer, const uint64_t* bp_off, uint64_t n_table, const double* bp_prob, int variant,
-                         int flags, gasm_scores** out) {
-    API_GUARD_BEGIN
-    if (!ctx || !out || !path_off || !read_off || !bp_off || (n_table && (!bp_kmer || !bp_prob)) || (true_len && !true_solution)) {
-        gasm_set_error("gasm_calc_breakscore: null argument");
-        return GASM_ERR_INVALID;
-    }
-    if (variant != GASM_SCORE_OWN && variant != GASM_SCORE_VELVET) { gasm_set_error("unknown variant %d", variant); return GASM_ERR_INVALID; }
-    if (n_paths > 0xFFFFFFF0ull) { gasm_set_error("too many paths"); return GASM_ERR_CAPACITY; }
-    *out = nullptr;
+// calc_breakscore proper.  `dp` holds the paths on the device (uploaded text or the scaffolds of a device-side
+// assemble_contigs); path_text(p) hands out path p as text for the few host-side steps that want it (the velvet variant's
+// startpos find, the host Levenshtein routine for a target outside ACGT).
+static int breakscore_impl(gasm_ctx* ctx, DevPaths& dp, const std::function<std::string(u64)>& path_text, uint64_t n_paths, const char* reads,
+                           const uint64_t* read_off, uint64_t n_reads, const char* true_solution, uint64_t true_len, int kmer,
+                           const char* bp_kmer, const uint64_t* bp_off, uint64_t n_table, const double* bp_prob, int variant,
+                           int flags, gasm_scores** out) {
     const bool velvet = variant == GASM_SCORE_VELVET;
     DevReads rd;
-    DevPaths dp;
     ScoreTable tb;
     ScoreState ss;
     const u64 seg_off[2] = {0, n_reads};
     static const char empty = 0;
     int st = rd.upload(ctx, reads ? reads : &empty, read_off, n_reads, 0, seg_off, 1);
-    if (st == GASM_OK) st = dp.upload_ascii(ctx, paths ? paths : &empty, path_off, (u32)n_paths);
     if (st == GASM_OK) st = tb.set(ctx, bp_kmer, bp_off, n_table, bp_prob);
     if (st == GASM_OK) st = pipeline_score_launch(ctx, rd, dp, kmer, tb, !velvet && (flags & GASM_WANT_FREQ), velvet, ss, nullptr);
     if (st == GASM_OK) st = pipeline_score_fetch(ctx, ss);
@@ -251,8 +372,7 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
             const std::string truth(true_solution ? true_solution : "", true_len);
             for (u64 p = 0; p < n_paths; ++p) {
                 if (ss.h_breaks[p] <= 0) continue;
-                const std::string pth(paths + path_off[p], paths + path_off[p + 1]);
-                s->startpos[p] = (int32_t)(int)truth.find(pth);
+                s->startpos[p] = (int32_t)(int)truth.find(path_text(p));
             }
         }
         if (flags & GASM_WANT_KS) {
@@ -269,7 +389,7 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
             u64 max_bands = 0;
             double cells = 0;
             for (u64 p = 0; p < n_paths; ++p) {
-                const u64 nq = path_off[p + 1] - path_off[p];
+                const u64 nq = dp.h_p_off[p + 1] - dp.h_p_off[p];
                 max_bands = std::max<u64>(max_bands, (nq + 4095) / 4096);
                 cells += (double)nq * (double)true_len;
             }
@@ -294,7 +414,8 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
                 while (true) {
                     const u64 p = next.fetch_add(1);
                     if (p >= n_paths) break;
-                    s->lev[p] = gasm_host::levenshtein(paths + path_off[p], path_off[p + 1] - path_off[p], true_solution, true_len, velvet);
+                    const std::string q = path_text(p);
+                    s->lev[p] = gasm_host::levenshtein(q.data(), q.size(), true_solution, true_len, velvet);
                 }
             };
             if (nt == 1) work();
@@ -305,10 +426,32 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
             }
         }
     }
-    rd.release(); dp.release(); tb.release(); ss.release();
+    rd.release(); tb.release(); ss.release();
     if (st != GASM_OK) { delete s; return st; }
     *out = s;
     return GASM_OK;
+}
+
+int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_off, uint64_t n_paths, const char* reads,
+                         const uint64_t* read_off, uint64_t n_reads, const char* true_solution, uint64_t true_len, int kmer,
+                         const char* bp_kmer, const uint64_t* bp_off, uint64_t n_table, const double* bp_prob, int variant,
+                         int flags, gasm_scores** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || !path_off || !read_off || !bp_off || (n_table && (!bp_kmer || !bp_prob)) || (true_len && !true_solution)) {
+        gasm_set_error("gasm_calc_breakscore: null argument");
+        return GASM_ERR_INVALID;
+    }
+    if (variant != GASM_SCORE_OWN && variant != GASM_SCORE_VELVET) { gasm_set_error("unknown variant %d", variant); return GASM_ERR_INVALID; }
+    if (n_paths > 0xFFFFFFF0ull) { gasm_set_error("too many paths"); return GASM_ERR_CAPACITY; }
+    *out = nullptr;
+    static const char empty = 0;
+    DevPaths dp;
+    int st = dp.upload_ascii(ctx, paths ? paths : &empty, path_off, (u32)n_paths);
+    if (st == GASM_OK)
+        st = breakscore_impl(ctx, dp, [&](u64 p) { return std::string(paths + path_off[p], paths + path_off[p + 1]); }, n_paths, reads, read_off, n_reads,
+                             true_solution, true_len, kmer, bp_kmer, bp_off, n_table, bp_prob, variant, flags, out);
+    dp.release();
+    return st;
     API_GUARD_END
 }
 

@@ -129,6 +129,8 @@ namespace gasm_host {
 void shuffle_perm(u64 n, int seed, u64 rows, std::vector<u32>& perm);
 // greedy merge + ordering of lib/DeNovoAssembler.cpp:228-304; returns GASM_ERR_RANGE where substr would throw.
 int assemble(const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k, std::vector<std::string>& out);
+// the index-form merge alone: sorted distinct chain signatures (u32 contig, u32 overlap, u32 contig, ...); false = not applicable
+bool assemble_signatures(const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k, std::vector<std::string>& sigs);
 // Myers bit-parallel edit distance; infix = edlib HW mode, else NW.
 int levenshtein(const char* q, u64 nq, const char* t, u64 nt, bool infix);
 // reads of sequence files, packed 2-bit back to back (seqio.cpp)

@@ -132,7 +132,7 @@ static void merge_indices(const std::vector<std::string>& contigs, const std::ve
     }
 }
 
-int assemble(const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k, std::vector<std::string>& out) {
+bool assemble_signatures(const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k, std::vector<std::string>& all) {
     const u64 n = row_len;
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 1;
@@ -140,37 +140,11 @@ int assemble(const std::vector<std::string>& contigs, const u32* perm, u64 rows,
     if (rows < 64) nt = 1;
     size_t min_len = ~(size_t)0;
     for (const std::string& s : contigs) min_len = std::min(min_len, s.size());
-    const bool by_index = n > 0 && k >= 2 && min_len >= (size_t)(k - 1) && n <= 4096;
+    all.clear();
+    if (!(n > 0 && k >= 2 && min_len >= (size_t)(k - 1) && n <= 4096)) return false;
     std::atomic<u64> next(0);
-    std::atomic<int> bad(0);
-    out.clear();
-    if (!by_index) {
-        // contigs shorter than an overlap (the reference throws there or compares whole strings): the string version
-        std::vector<std::vector<std::string>> per(rows);
-        auto work = [&]() {
-            std::vector<std::string> c;
-            while (true) {
-                const u64 r = next.fetch_add(1);
-                if (r >= rows || bad.load()) break;
-                c.resize(n);
-                for (u64 j = 0; j < n; ++j) c[j] = contigs[perm[r * n + j]];
-                if (!merge_one(c, k)) { bad.store(1); break; }
-                per[r] = c;
-            }
-        };
-        if (nt == 1) work();
-        else {
-            std::vector<std::thread> th;
-            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work);
-            for (auto& t : th) t.join();
-        }
-        if (bad.load()) {
-            gasm_set_error("assemble_contigs: a contig is shorter than the overlap being tried (the reference throws std::out_of_range here)");
-            return GASM_ERR_RANGE;
-        }
-        for (auto& v : per) for (auto& s : v) out.push_back(std::move(s));
-    } else {
-        const bool timing = getenv("GASM_ASM_TIMING") != nullptr;
+    {
+        const bool timing = false;
         auto tnow = []() { return std::chrono::steady_clock::now(); };
         auto t0 = tnow();
         auto lap = [&](const char* what) { if (timing) { auto t1 = tnow(); fprintf(stderr, "[assemble] %-22s %8.1f ms\n", what, std::chrono::duration<double>(t1 - t0).count() * 1e3); t0 = t1; } };
@@ -213,11 +187,64 @@ int assemble(const std::vector<std::string>& contigs, const u32* perm, u64 rows,
             for (auto& t : th) t.join();
         }
         lap("match + merges");
-        std::vector<std::string> all;
         for (auto& v : sigs) for (auto& s : v) all.push_back(std::move(s));
         std::sort(all.begin(), all.end());
         all.erase(std::unique(all.begin(), all.end()), all.end());
         lap("signature sort+unique");
+    }
+    return true;
+}
+
+// The index-form merge alone: every permutation's final chains as signatures (contig, overlap, contig, ... as 32-bit
+// words), sorted and de-duplicated.  false = the index form does not apply (a contig shorter than k-1, or more than 4096
+// contigs): the caller takes the string form.
+bool assemble_signatures(const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k, std::vector<std::string>& sigs_out);
+
+int assemble(const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k, std::vector<std::string>& out) {
+    const u64 n = row_len;
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 32) nt = 32;
+    if (rows < 64) nt = 1;
+    size_t min_len = ~(size_t)0;
+    for (const std::string& s : contigs) min_len = std::min(min_len, s.size());
+    const bool by_index = n > 0 && k >= 2 && min_len >= (size_t)(k - 1) && n <= 4096;
+    std::atomic<u64> next(0);
+    std::atomic<int> bad(0);
+    out.clear();
+    if (!by_index) {
+        // contigs shorter than an overlap (the reference throws there or compares whole strings): the string version
+        std::vector<std::vector<std::string>> per(rows);
+        auto work = [&]() {
+            std::vector<std::string> c;
+            while (true) {
+                const u64 r = next.fetch_add(1);
+                if (r >= rows || bad.load()) break;
+                c.resize(n);
+                for (u64 j = 0; j < n; ++j) c[j] = contigs[perm[r * n + j]];
+                if (!merge_one(c, k)) { bad.store(1); break; }
+                per[r] = c;
+            }
+        };
+        if (nt == 1) work();
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work);
+            for (auto& t : th) t.join();
+        }
+        if (bad.load()) {
+            gasm_set_error("assemble_contigs: a contig is shorter than the overlap being tried (the reference throws std::out_of_range here)");
+            return GASM_ERR_RANGE;
+        }
+        for (auto& v : per) for (auto& s : v) out.push_back(std::move(s));
+    } else {
+        const bool timing = getenv("GASM_ASM_TIMING") != nullptr;
+        auto tnow = []() { return std::chrono::steady_clock::now(); };
+        auto t0 = tnow();
+        auto lap = [&](const char* what) { if (timing) { auto t1 = tnow(); fprintf(stderr, "[assemble] %-22s %8.1f ms\n", what, std::chrono::duration<double>(t1 - t0).count() * 1e3); t0 = t1; } };
+        std::vector<std::string> all;
+        assemble_signatures(contigs, perm, rows, row_len, k, all);
+        lap("signatures");
         // one string per distinct signature (threads over signatures)
         out.resize(all.size());
         std::atomic<u64> nx(0);

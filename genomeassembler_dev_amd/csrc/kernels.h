@@ -118,6 +118,13 @@ __global__ void k_bucket_merge(const K* in_keys, const u32* in_cnt, const u64* r
                                const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits);
 __global__ void k_repack_reads(const u64* src, const u64* dir, u64* words_out);
 
+// ---- kernels_asm.hip
+__global__ void k_chain_expand(const u64* cwords, const u64* c_off, const u64* sig_off, const u32* elem_contig, const u32* elem_skip, const u64* elem_pos,
+                               const u64* out_off, u32 n_scaffolds, u64* out, u64 n_words);
+__global__ void k_str_bitonic(const u64* words, const u64* off, u32* idx, u32 n_pow2, u32 kk, u32 j);
+__global__ void k_str_adjacent_eq(const u64* words, const u64* off, const u32* idx, u32 n, u8* same_as_prev);
+__global__ void k_unpack_ascii(const u64* words, u64 nbases, u8* out);
+
 // ---- kernels_sim.hip
 __global__ void k_sim_weights(const u64* gwords, const u64* gbase, const u64* woff, u32 n_segments, int kmer, const long long* fixw, u64* w);
 template <class T> __global__ void k_seg_scan_incl(T* a, const u64* off);

@@ -1,0 +1,83 @@
+// kernels_asm.hip — scaffolds of assemble_contigs kept on the device (lib/DeNovoAssembler.cpp:228-304,
+// lib/BreakageScorer.cpp:85-172).  A scaffold is a chain of whole contigs glued with overlaps (host_algos.cpp: the greedy
+// merge runs on contig indices); here the chains become 2-bit sequences in HBM, are ordered and de-duplicated as strings
+// (the reference's sort + unique on std::string: plain lexicographic, a proper prefix first), and stay there for
+// calc_breakscore — the 3.8e8 characters of a 50 kb experiment never exist as host strings unless somebody fetches them.
+//   k_chain_expand    chains -> one packed base stream (scaffold after scaffold, no gaps): a thread per output word
+//   k_str_bitonic     one compare-exchange step of a bitonic sort of scaffold indices, comparing packed sequences
+//   k_str_adjacent_eq equal neighbours in the sorted order (std::unique)
+//   k_unpack_ascii    2-bit -> text, for a fetch
+#include "device_utils.h"
+#include "kernels.h"
+
+__device__ __forceinline__ u32 base_at(const u64* __restrict__ w, u64 p) { return (u32)(w[p >> 5] >> (62 - 2 * (p & 31))) & 3u; }
+
+// Scaffold m = elements [sig_off[m], sig_off[m+1]); element e contributes contig elem_contig[e] without its first
+// elem_skip[e] bases, starting at base elem_pos[e] of the scaffold; scaffold m occupies bases [out_off[m], out_off[m+1]).
+__global__ void __launch_bounds__(GASM_WG) k_chain_expand(const u64* __restrict__ cwords, const u64* __restrict__ c_off, const u64* __restrict__ sig_off,
+                                                          const u32* __restrict__ elem_contig, const u32* __restrict__ elem_skip,
+                                                          const u64* __restrict__ elem_pos, const u64* __restrict__ out_off, u32 n_scaffolds,
+                                                          u64* __restrict__ out, u64 n_words) {
+    const u64 total = out_off[n_scaffolds];
+    for (u64 w = (u64)blockIdx.x * GASM_WG + threadIdx.x; w < n_words; w += (u64)gridDim.x * GASM_WG) {
+        u64 g = w << 5, v = 0;
+        if (g < total) {
+            u32 m = upper_seg<u64>(out_off, n_scaffolds, g);              // scaffold of the word's first base
+            while (out_off[m + 1] <= g) ++m;                               // (empty scaffolds share an offset)
+            u64 e0 = sig_off[m], e1 = sig_off[m + 1];
+            u64 rel = g - out_off[m];
+            u64 e = e0 + upper_seg<u64>(elem_pos + e0, (u32)(e1 - e0), rel);
+            for (u32 b = 0; b < 32 && g < total; ++b, ++g) {
+                while (g >= out_off[m + 1]) { ++m; e0 = sig_off[m]; e1 = sig_off[m + 1]; e = e0; }
+                rel = g - out_off[m];
+                while (e + 1 < e1 && elem_pos[e + 1] <= rel) ++e;
+                const u64 src = c_off[elem_contig[e]] + elem_skip[e] + (rel - elem_pos[e]);
+                v |= (u64)base_at(cwords, src) << (62 - 2 * b);
+            }
+        }
+        out[w] = v;
+    }
+}
+
+// sequence a < sequence b (lexicographic over bases, a proper prefix first); *eq = equal
+__device__ __forceinline__ bool seq_less(const u64* __restrict__ words, u64 oa, u64 la, u64 ob, u64 lb, bool* eq) {
+    const u64 n = la < lb ? la : lb;
+    for (u64 t = 0; t < n; t += 32) {
+        u64 va = window32(words, oa + t), vb = window32(words, ob + t);
+        const u64 left = n - t;
+        if (left < 32) { const u64 mk = ~0ull << (64 - 2 * left); va &= mk; vb &= mk; }
+        if (va != vb) { *eq = false; return va < vb; }
+    }
+    *eq = la == lb;
+    return la < lb;
+}
+
+__global__ void __launch_bounds__(GASM_WG) k_str_bitonic(const u64* __restrict__ words, const u64* __restrict__ off, u32* __restrict__ idx, u32 n_pow2,
+                                                         u32 kk, u32 j) {
+    const u32 t = blockIdx.x * GASM_WG + threadIdx.x;
+    if (t >= (n_pow2 >> 1)) return;
+    const u32 lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+    const u32 a = idx[lo], b = idx[hi];
+    bool swap;
+    if (a == GASM_NONE32 || b == GASM_NONE32) swap = (a == GASM_NONE32 && b != GASM_NONE32);      // padding sorts last
+    else {
+        bool eq;
+        const bool b_less = seq_less(words, off[b], off[b + 1] - off[b], off[a], off[a + 1] - off[a], &eq);
+        swap = b_less || (eq && b < a);            // equal strings: by index (any fixed order will do: they are merged)
+    }
+    const bool up = (lo & kk) == 0;
+    if (swap == up) { idx[lo] = b; idx[hi] = a; }
+}
+
+__global__ void __launch_bounds__(GASM_WG) k_str_adjacent_eq(const u64* __restrict__ words, const u64* __restrict__ off, const u32* __restrict__ idx, u32 n,
+                                                             u8* __restrict__ same_as_prev) {
+    const u32 i = blockIdx.x * GASM_WG + threadIdx.x;
+    if (i >= n) return;
+    bool eq = false;
+    if (i) { const u32 a = idx[i - 1], b = idx[i]; (void)seq_less(words, off[a], off[a + 1] - off[a], off[b], off[b + 1] - off[b], &eq); }
+    same_as_prev[i] = eq ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(GASM_WG) k_unpack_ascii(const u64* __restrict__ words, u64 nbases, u8* __restrict__ out) {
+    for (u64 p = (u64)blockIdx.x * GASM_WG + threadIdx.x; p < nbases; p += (u64)gridDim.x * GASM_WG) out[p] = "ACGT"[base_at(words, p)];
+}

@@ -1,0 +1,14 @@
+// scaffolds.h — device-resident result of assemble_contigs (scaffolds.hip)
+#pragma once
+#include "pipeline.h"
+
+struct gasm_scaffolds {
+    gasm_ctx* ctx = nullptr;
+    DBuf d_words;               // 2-bit, scaffold after scaffold without gaps, + 4 padding words
+    std::vector<u64> h_off;     // n + 1 base offsets, final (reference) order: longest first
+    u32 n = 0;
+};
+
+int scaffolds_from_signatures(gasm_ctx* ctx, const std::vector<std::string>& contigs, const std::vector<std::string>& sigs, gasm_scaffolds** out);
+int scaffolds_fetch(const gasm_scaffolds* sc, std::vector<char>& data, std::vector<u64>& off);
+int scaffolds_as_paths(const gasm_scaffolds* sc, DevPaths& dp);

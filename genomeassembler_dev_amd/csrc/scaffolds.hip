@@ -1,0 +1,154 @@
+// scaffolds.hip — assemble_contigs with its result kept on the device.  The greedy merge itself runs
+// on contig indices (host_algos.cpp: same visiting order as lib/DeNovoAssembler.cpp:233-266, threads over permutations,
+// ~4 ms for 10 000 permutations); what used to cost the time — building 3.8e8 characters of scaffold text, handing them
+// to the caller and uploading them again for calc_breakscore — is replaced by chains expanded to 2-bit on the GPU
+// (kernels_asm.hip), sorted and de-duplicated there as strings, and passed on behind a gasm_scaffolds handle.
+#include <algorithm>
+
+#include "pipeline.h"
+#include "scaffolds.h"
+
+static int up64(gasm_ctx* ctx, DBuf& b, const void* src, size_t bytes) {
+    GCHK(b.ensure(bytes ? bytes : 8));
+    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return GASM_OK;
+}
+
+struct ChainCsr {
+    std::vector<u64> sig_off, elem_pos, out_off;
+    std::vector<u32> elem_contig, elem_skip;
+    void clear() { sig_off.assign(1, 0); out_off.assign(1, 0); elem_pos.clear(); elem_contig.clear(); elem_skip.clear(); }
+    // signature = u32 contig, (u32 overlap, u32 contig)*
+    void add(const std::string& sg, const std::vector<std::string>& contigs) {
+        u32 x;
+        memcpy(&x, sg.data(), 4);
+        u64 pos = 0;
+        elem_contig.push_back(x); elem_skip.push_back(0); elem_pos.push_back(0);
+        pos += contigs[x].size();
+        for (size_t q = 4; q + 8 <= sg.size(); q += 8) {
+            u32 ov, y;
+            memcpy(&ov, sg.data() + q, 4);
+            memcpy(&y, sg.data() + q + 4, 4);
+            elem_contig.push_back(y); elem_skip.push_back(ov); elem_pos.push_back(pos);
+            pos += contigs[y].size() - ov;
+        }
+        sig_off.push_back(elem_contig.size());
+        out_off.push_back(out_off.back() + pos);
+    }
+};
+
+static int expand(gasm_ctx* ctx, const ChainCsr& c, const u64* d_cwords, const u64* d_coff, DBuf& d_out, DBuf (&tmp)[5]) {
+    const u32 m = (u32)(c.sig_off.size() - 1);
+    const u64 T = c.out_off[m], nw = (T + 31) / 32 + 4;
+    GCHK(up64(ctx, tmp[0], c.sig_off.data(), c.sig_off.size() * 8));
+    GCHK(up64(ctx, tmp[1], c.elem_contig.data(), c.elem_contig.size() * 4));
+    GCHK(up64(ctx, tmp[2], c.elem_skip.data(), c.elem_skip.size() * 4));
+    GCHK(up64(ctx, tmp[3], c.elem_pos.data(), c.elem_pos.size() * 8));
+    GCHK(up64(ctx, tmp[4], c.out_off.data(), c.out_off.size() * 8));
+    GCHK(d_out.ensure(nw * 8));
+    GLAUNCH(ctx, "k_chain_expand", k_chain_expand, dim3(std::max(1u, std::min<u32>(ceil_div_u64(nw, GASM_WG), (u32)ctx->n_cu * 16u))), dim3(GASM_WG), 0, d_cwords,
+            d_coff, tmp[0].as<u64>(), tmp[1].as<u32>(), tmp[2].as<u32>(), tmp[3].as<u64>(), tmp[4].as<u64>(), m, d_out.as<u64>(), nw);
+    return GASM_OK;
+}
+
+int scaffolds_from_signatures(gasm_ctx* ctx, const std::vector<std::string>& contigs, const std::vector<std::string>& sigs, gasm_scaffolds** out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    const u32 n = (u32)contigs.size(), m = (u32)sigs.size();
+    DBuf ascii, err, cwords, d_coff, d_w1, d_idx, d_same, tmp[5];
+    struct Rel { std::vector<DBuf*> v; ~Rel() { for (DBuf* b : v) b->release(); } } rel{{&ascii, &err, &cwords, &d_coff, &d_w1, &d_idx, &d_same, &tmp[0], &tmp[1],
+                                                                                         &tmp[2], &tmp[3], &tmp[4]}};
+    // ---- contigs, packed
+    std::vector<u64> coff((size_t)n + 1, 0);
+    std::string cat;
+    for (u32 i = 0; i < n; ++i) { cat += contigs[i]; coff[i + 1] = cat.size(); }
+    GCHK(err.ensure(8));
+    HIPCHK(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+    GCHK(up64(ctx, ascii, cat.data(), cat.size()));
+    {
+        const u64 nw = (cat.size() + 31) / 32;
+        GCHK(cwords.ensure((nw + 4) * 8));
+        GLAUNCH(ctx, "k_pack_ascii", k_pack_ascii, dim3(std::max(1u, std::min<u32>(ceil_div_u64(nw + 4, GASM_WG), (u32)ctx->n_cu * 32u))), dim3(GASM_WG), 0, ascii.as<u8>(),
+                (u64)cat.size(), (const u64*)nullptr, cwords.as<u64>(), err.as<u32>());
+    }
+    GCHK(up64(ctx, d_coff, coff.data(), coff.size() * 8));
+    // ---- every distinct chain once, as text-in-2-bit; sort and de-duplicate as strings (lib/DeNovoAssembler.cpp:275-286)
+    ChainCsr c1;
+    c1.clear();
+    for (const std::string& sg : sigs) c1.add(sg, contigs);
+    GCHK(expand(ctx, c1, cwords.as<u64>(), d_coff.as<u64>(), d_w1, tmp));
+    u32 p2 = 1;
+    while (p2 < m) p2 <<= 1;
+    std::vector<u32> idx(p2, GASM_NONE32);
+    for (u32 i = 0; i < m; ++i) idx[i] = i;
+    GCHK(up64(ctx, d_idx, idx.data(), (size_t)p2 * 4));
+    for (u32 kk = 2; kk <= p2; kk <<= 1)
+        for (u32 j = kk >> 1; j > 0; j >>= 1)
+            GLAUNCH(ctx, "k_str_bitonic", k_str_bitonic, dim3(std::max(1u, ceil_div_u64(p2 >> 1, GASM_WG))), dim3(GASM_WG), 0, d_w1.as<u64>(), tmp[4].as<u64>(),
+                    d_idx.as<u32>(), p2, kk, j);
+    GCHK(d_same.ensure(std::max<u32>(m, 1)));
+    if (m) GLAUNCH(ctx, "k_str_adjacent_eq", k_str_adjacent_eq, dim3(ceil_div_u64(m, GASM_WG)), dim3(GASM_WG), 0, d_w1.as<u64>(), tmp[4].as<u64>(), d_idx.as<u32>(), m,
+                   d_same.as<u8>());
+    std::vector<u8> same(m);
+    u32 herr = 0;
+    HIPCHK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (m) {
+        HIPCHK(hipMemcpyAsync(idx.data(), d_idx.p, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(same.data(), d_same.p, m, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (herr) { gasm_set_error("contigs contain a base outside upper-case ACGT"); return GASM_ERR_NON_ACGT; }
+    // ---- the reference's last step: the sorted distinct strings, then std::sort by length, longest first
+    // (lib/DeNovoAssembler.cpp:289-294: not a stable sort; the same libstdc++ call on the same initial order makes the same
+    // comparisons and moves, whatever the elements carry)
+    struct Ent { u64 len; u32 id; };
+    std::vector<Ent> fin;
+    for (u32 i = 0; i < m; ++i) if (!same[i]) fin.push_back(Ent{c1.out_off[idx[i] + 1] - c1.out_off[idx[i]], idx[i]});
+    std::sort(fin.begin(), fin.end(), [](const Ent& a, const Ent& b) { return a.len > b.len; });
+    // ---- the distinct scaffolds in their final order, once more, as the handle's stream
+    ChainCsr c2;
+    c2.clear();
+    for (const Ent& e : fin) c2.add(sigs[e.id], contigs);
+    gasm_scaffolds* sc = new gasm_scaffolds();
+    sc->ctx = ctx;
+    sc->n = (u32)fin.size();
+    sc->h_off = c2.out_off;
+    int st = expand(ctx, c2, cwords.as<u64>(), d_coff.as<u64>(), sc->d_words, tmp);
+    if (st == GASM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { gasm_set_error("scaffold expansion failed"); st = GASM_ERR_HIP; }
+    if (st != GASM_OK) { sc->d_words.release(); delete sc; return st; }
+    *out = sc;
+    return GASM_OK;
+}
+
+int scaffolds_fetch(const gasm_scaffolds* sc, std::vector<char>& data, std::vector<u64>& off) {
+    gasm_ctx* ctx = sc->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    off = sc->h_off;
+    const u64 T = sc->h_off[sc->n];
+    data.resize(T);
+    if (T == 0) return GASM_OK;
+    DBuf d;
+    GCHK(d.ensure(T));
+    hipLaunchKernelGGL(k_unpack_ascii, dim3(std::min<u32>(ceil_div_u64(T, GASM_WG), (u32)ctx->n_cu * 32u)), dim3(GASM_WG), 0, ctx->stream, sc->d_words.as<u64>(), T, d.as<u8>());
+    hipError_t e = hipMemcpyAsync(data.data(), d.p, T, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    d.release();
+    if (e != hipSuccess) { gasm_set_error("scaffold fetch failed: %s", hipGetErrorString(e)); return GASM_ERR_HIP; }
+    return GASM_OK;
+}
+
+// the scaffolds as the paths of a scoring call
+int scaffolds_as_paths(const gasm_scaffolds* sc, DevPaths& dp) {
+    gasm_ctx* ctx = sc->ctx;
+    HIPCHK(hipSetDevice(ctx->device));
+    dp.n_segments = 1;
+    dp.n_paths = sc->n;
+    dp.b_p_off = nullptr; dp.b_seg_path_off = nullptr; dp.b_seg_base_off = nullptr;
+    dp.h_p_off = sc->h_off;
+    dp.total_bases = sc->h_off[sc->n];
+    if (dp.total_bases >= 0xFFFFFFF0ull) { gasm_set_error("paths exceed 2^32 bases"); return GASM_ERR_CAPACITY; }
+    dp.h_seg_path_off = {0u, sc->n};
+    const u64 nw = (dp.total_bases + 31) / 32 + 4;
+    GCHK(dp.d_words.ensure(nw * 8));
+    HIPCHK(hipMemcpyAsync(dp.d_words.p, sc->d_words.p, nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return dp.upload_dirs(ctx);
+}

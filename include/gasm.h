@@ -96,6 +96,18 @@ int gasm_assemble_contigs(gasm_ctx* ctx, const char* contigs, const uint64_t* of
                           uint64_t rows, uint64_t row_len, int dbg_kmer, gasm_strlist** out);
 int gasm_assemble_contigs_velvet(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, int dbg_kmer,
                                  int seed, int rows, gasm_strlist** out);
+/* The same two functions with the scaffolds left on the GPU (2-bit, the reference's order: longest first) behind a handle
+ * that gasm_calc_breakscore_dev takes as its `path` argument: the text of the scaffolds (3.8e8 characters for one 50 kb
+ * experiment) is only made when gasm_scaffolds_fetch asks for it.  Same results as the string forms. */
+typedef struct gasm_scaffolds gasm_scaffolds;
+int gasm_assemble_contigs_dev(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, const uint32_t* perm,
+                              uint64_t rows, uint64_t row_len, int dbg_kmer, gasm_scaffolds** out);
+int gasm_assemble_contigs_velvet_dev(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, int dbg_kmer, int seed,
+                                     int rows, gasm_scaffolds** out);
+uint64_t gasm_scaffolds_count(const gasm_scaffolds* s);
+const uint64_t* gasm_scaffolds_offsets(const gasm_scaffolds* s);   /* count + 1 base offsets: lengths without a fetch */
+int gasm_scaffolds_fetch(const gasm_scaffolds* s, gasm_strlist** out);
+void gasm_scaffolds_free(gasm_scaffolds* s);
 uint64_t gasm_strlist_count(const gasm_strlist* s);
 const char* gasm_strlist_data(const gasm_strlist* s);
 const uint64_t* gasm_strlist_offsets(const gasm_strlist* s);
@@ -125,6 +137,10 @@ int gasm_calc_breakscore(gasm_ctx* ctx, const char* paths, const uint64_t* path_
                          const char* reads, const uint64_t* read_off, uint64_t n_reads, const char* true_solution,
                          uint64_t true_len, int kmer, const char* bp_kmer, const uint64_t* bp_off, uint64_t n_table,
                          const double* bp_prob, int variant, int flags, gasm_scores** out);
+/* calc_breakscore of device-resident scaffolds (gasm_assemble_contigs_dev); everything else as gasm_calc_breakscore */
+int gasm_calc_breakscore_dev(gasm_ctx* ctx, const gasm_scaffolds* paths, const char* reads, const uint64_t* read_off, uint64_t n_reads,
+                             const char* true_solution, uint64_t true_len, int kmer, const char* bp_kmer, const uint64_t* bp_off,
+                             uint64_t n_table, const double* bp_prob, int variant, int flags, gasm_scores** out);
 uint64_t gasm_scores_count(const gasm_scores* s);
 const int32_t* gasm_scores_sequence_len(const gasm_scores* s);
 const double* gasm_scores_bp_score(const gasm_scores* s);

@@ -653,3 +653,50 @@ def test_read_simulator_against_oracle(qtable):
     expect_ratio = y[hi] / y[lo]
     assert cnt[hi] > cnt[lo] and 0.5 * expect_ratio < (cnt[hi] + 1) / (cnt[lo] + 1) < 2.0 * expect_ratio
     b.close()
+
+
+def test_device_resident_scaffolds(qtable):
+    """assemble_contigs with the result left on the GPU (chains expanded to 2-bit, ordered and de-duplicated as strings
+    there) and calc_breakscore fed from the handle: the scaffold list, its order and every score equal the oracle's; the
+    string form of the same call goes through the same device route when it is given a context"""
+    keys, prob = qtable
+    rng = np.random.default_rng(13)
+    for seed, L, rl, cov, k, rows in ((61, 1500, 24, 40, 15, 400), (62, 2500, 30, 35, 17, 900), (63, 800, 20, 30, 9, 150)):
+        g = synth.make_segment(seed, L, n_short=4, short_len=50, n_long=2, long_len=120, tandem_len=40, planted=True)
+        truth = g.tobytes().decode()
+        reads = _strs(synth.simulate_reads(g, rl, cov, seed + 1))
+        km = ga.get_kmers_from_reads(reads, k)
+        m = ga.get_contigs(km, k, 1234, matrix_rows=rows)
+        ref = orc.assemble_contigs(m.contigs, m.perm, k)
+        sc = ga.assemble_contigs(m, k, on_device=True)
+        assert len(sc) == len(ref) and sc.lengths.tolist() == [len(s) for s in ref]
+        assert sc.strings() == ref
+        assert ga.assemble_contigs(m, k, ctx=ga.default_context()) == ref
+        for variant in ("own", "velvet"):
+            mine = ga.calc_breakscore(sc, reads, truth, 8, keys, prob, variant=variant, with_lev=True, with_freq=False, with_ks=(variant == "own"))
+            o = orc.calc_breakscore(ref, reads, truth, 8, keys, prob, velvet=(variant == "velvet"), with_lev=True, with_freq=(variant == "own"))
+            _check_scores(mine, o, with_lev=True)
+            if variant == "velvet":
+                assert mine["path_prob_dist_startpos"].tolist() == o["path_prob_dist_startpos"].tolist()
+            else:
+                y = orc.kmer_from_seq(truth, 8, keys, prob)
+                for i in range(0, len(ref), max(1, len(ref) // 25)):
+                    r = orc.ks_statistic(o["path_freq"][i], y)
+                    assert (np.isnan(r) and np.isnan(mine["stat_test_KS"][i])) or abs(mine["stat_test_KS"][i] - r) < 1e-9
+        sc.close()
+    # the velvet entry (its own 20 000 shuffles), contigs that are not contigs of one graph
+    contigs = sorted(set(truth[a:a + int(rng.integers(20, 90))] for a in rng.integers(0, len(truth) - 90, 14)))
+    ref = orc.assemble_contigs_velvet(contigs, 11, 5, rows=300)
+    sc = ga.assemble_contigs_velvet(contigs, 11, 5, rows=300, on_device=True)
+    assert sc.strings() == ref
+    sc.close()
+    # a contig shorter than k-1: the string form behind the same handle
+    short = ["ACGTACGTAA", "ACG", "GTAAACCCGGGT", "TTTTTTTTTT"]
+    try:
+        ref = orc.assemble_contigs_velvet(short, 4, 2, rows=40)
+    except IndexError:
+        ref = None
+    if ref is not None:
+        sc = ga.assemble_contigs_velvet(short, 4, 2, rows=40, on_device=True)
+        assert sc.strings() == ref
+        sc.close()

@@ -30,7 +30,14 @@ def timed(name, f):
 
 km = timed("get_kmers_from_reads (host)", lambda: ga.get_kmers_from_reads(reads, k))
 m = timed(f"get_contigs ({rows} shuffles)", lambda: ga.get_contigs(km, k, 1234, matrix_rows=rows))
-sc = timed("assemble_contigs (host merge)", lambda: ga.assemble_contigs(m, k))
+sc = timed("assemble_contigs (strings back)", lambda: ga.assemble_contigs(m, k, ctx=ga.default_context()))
 print(f"  contigs {len(m.contigs)}, scaffolds {len(sc)}, scaffold bases {sum(map(len, sc))}")
-timed("calc_breakscore, no lev", lambda: ga.calc_breakscore(sc, reads, truth, 8, keys, prob, with_lev=False, with_freq=False))
-timed("calc_breakscore, with lev (GPU)", lambda: ga.calc_breakscore(sc, reads, truth, 8, keys, prob, with_lev=True, with_freq=False))
+a = timed("calc_breakscore(strings), no lev", lambda: ga.calc_breakscore(sc, reads, truth, 8, keys, prob, with_lev=False, with_freq=False))
+timed("calc_breakscore(strings), with lev", lambda: ga.calc_breakscore(sc, reads, truth, 8, keys, prob, with_lev=True, with_freq=False))
+# the same experiment with the scaffolds left on the GPU between the two calls (gasm_assemble_contigs_dev / _calc_breakscore_dev)
+dv = timed("assemble_contigs (on device)", lambda: ga.assemble_contigs(m, k, on_device=True))
+b = timed("calc_breakscore(handle), no lev", lambda: ga.calc_breakscore(dv, reads, truth, 8, keys, prob, with_lev=False, with_freq=False))
+timed("calc_breakscore(handle), lev + KS", lambda: ga.calc_breakscore(dv, reads, truth, 8, keys, prob, with_lev=True, with_freq=False, with_ks=True))
+assert len(dv) == len(sc) and (a["kmer_breaks"] == b["kmer_breaks"]).all() and abs(a["bp_score"] - b["bp_score"]).max() == 0.0
+os.environ["GASM_ASM_HOST"] = "1"
+timed("assemble_contigs (host strings)", lambda: ga.assemble_contigs(m, k))
