@@ -186,7 +186,7 @@ def main():
             tp = found[-1]      # the most recent committed pass (tools/profile_round.sh + tools/pmc_traffic.py)
             tj = json.load(open(tp))
             for name, v in tj.items():
-                if name.startswith(dom):
+                if name.startswith(dom) and isinstance(v, dict):
                     roofline["traffic"] = int(v["FETCH_x2_bytes"] + v["WRITE_SIZE_bytes"])
                     roofline["traffic_source"] = os.path.relpath(tp, ROOT) + " (separate rocprofv3 --pmc passes, FETCH_SIZE x2)"
                     if "_measured_at" in tj:
