@@ -11,6 +11,7 @@
 // [[Rcpp::plugins("cpp17")]]
 #include <Rcpp.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
