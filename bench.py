@@ -73,10 +73,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # GASM_BENCH_BACKEND=gloo + GASM_BENCH_ONE_GPU=1: rehearsal of the multi-rank flow on a one-GPU box (all ranks share
+    # GPU 0, exchanges staged through the host) — never what the driver runs
+    backend = os.environ.get("GASM_BENCH_BACKEND", "nccl")
+    if os.environ.get("GASM_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import genomeassembler_dev_amd as ga
     from genomeassembler_dev_amd import parallel, pooled, qtable, synth
@@ -113,7 +121,7 @@ def main():
         if profile:
             prof = ctx.profile_read()
             ctx.profile(False)
-        return parallel.max_over_ranks(dt, device="cuda"), prof
+        return parallel.max_over_ranks(dt, device="cuda" if backend == "nccl" else "cpu"), prof
 
     # ---- the pooled partition of the global batch: this rank's every world-th read of every segment
     def pooled_setup():

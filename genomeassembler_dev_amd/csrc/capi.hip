@@ -181,7 +181,10 @@ static int assemble_device(gasm_ctx* ctx, const char* contigs, const u64* off, u
         if (perm[i] >= n) { gasm_set_error("perm[%llu] = %u out of range", (unsigned long long)i, perm[i]); return GASM_ERR_INVALID; }
     if (row_len != n) return GASM_OK;                       // (rows that are not permutations of all contigs: the string form)
     std::vector<std::string> sigs;
-    if (!gasm_host::assemble_signatures(c, perm, rows, row_len, k, sigs)) return GASM_OK;
+    bool on_gpu = false;
+    // the merge itself on the GPU (a wave per permutation); GASM_ASM_HOST_MERGE=1: on host threads (same signatures)
+    if (!getenv("GASM_ASM_HOST_MERGE")) GCHK(assemble_signatures_device(ctx, c, perm, rows, row_len, k, sigs, &on_gpu, nullptr));
+    if (!on_gpu && !gasm_host::assemble_signatures(c, perm, rows, row_len, k, sigs)) return GASM_OK;
     *used = true;
     return scaffolds_from_signatures(ctx, c, sigs, out);
 }

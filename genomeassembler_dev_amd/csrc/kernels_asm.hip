@@ -81,3 +81,110 @@ __global__ void __launch_bounds__(GASM_WG) k_str_adjacent_eq(const u64* __restri
 __global__ void __launch_bounds__(GASM_WG) k_unpack_ascii(const u64* __restrict__ words, u64 nbases, u8* __restrict__ out) {
     for (u64 p = (u64)blockIdx.x * GASM_WG + threadIdx.x; p < nbases; p += (u64)gridDim.x * GASM_WG) out[p] = "ACGT"[base_at(words, p)];
 }
+
+// ================================================================================================================
+// The greedy merge itself (lib/DeNovoAssembler.cpp:233-266; lib/BreakageScorer.cpp:96-149), on contig indices as in
+// host_algos.cpp (merge_indices): a merged string is a chain of whole contigs, and "suffix(c_i, ov) == prefix(c_j, ov)" is a
+// statement about the chain's LAST contig and the other chain's FIRST contig only, so the tests of all (overlap, contig,
+// contig) triples are made once (k_asm_match) and a permutation's merge is the reference's loop over small integers.
+// One wave per permutation: the outer loops (overlap, repeat-until-stable, i) run as the reference writes them; the inner
+// scan "for j from the back, the first chain whose head matches my tail" is 64 candidates per step with a ballot; the
+// chain table lives in LDS.  Two chains of equal length whose tail/head match need the reference's full-string test
+// `c[i] != c[j]`: such a permutation is handed back to the host routine (need_host), it is rare.
+// ================================================================================================================
+__global__ void __launch_bounds__(GASM_WG) k_asm_match(const u64* __restrict__ cwords, const u64* __restrict__ c_off, u32 n, int k,
+                                                       u8* __restrict__ match, u8* __restrict__ row_any, u8* __restrict__ level_any) {
+    const u64 total = (u64)(k - 1) * n * n;
+    for (u64 t = (u64)blockIdx.x * GASM_WG + threadIdx.x; t < total; t += (u64)gridDim.x * GASM_WG) {
+        const u32 b = (u32)(t % n), a = (u32)((t / n) % n);
+        const int ov = 1 + (int)(t / ((u64)n * n));
+        const u64 pa = c_off[a + 1] - ov, pb = c_off[b];         // (every contig has at least k-1 >= ov bases: host precondition)
+        bool eq = true;
+        for (int o = 0; o < ov && eq; o += 32) {
+            u64 va = window32(cwords, pa + o), vb = window32(cwords, pb + o);
+            const int left = ov - o;
+            if (left < 32) { const u64 mk = ~0ull << (64 - 2 * left); va &= mk; vb &= mk; }
+            eq = va == vb;
+        }
+        match[((u64)ov * n + a) * n + b] = eq ? 1 : 0;
+        if (eq && a != b) { row_any[(u64)ov * n + a] = 1; level_any[ov] = 1; }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_asm_merge(const u32* __restrict__ perm, u32 rows, u32 n, int k, const u32* __restrict__ clen,
+                                                  const u8* __restrict__ match, const u8* __restrict__ row_any, const u8* __restrict__ level_any,
+                                                  u32* __restrict__ out_next, u8* __restrict__ out_ov, u32* __restrict__ out_heads,
+                                                  u32* __restrict__ out_nchains, u8* __restrict__ need_host) {
+    extern __shared__ u32 sm[];
+    u32* head = sm;
+    u32* tail = sm + n;
+    u32* len = sm + 2 * n;
+    u8* emp = reinterpret_cast<u8*>(sm + 3 * n);
+    const u32 lane = threadIdx.x;
+    for (u32 r = blockIdx.x; r < rows; r += gridDim.x) {
+        const u64 rb = (u64)r * n;
+        for (u32 p = lane; p < n; p += 64) {
+            const u32 c = perm[rb + p];
+            head[p] = c; tail[p] = c; len[p] = clen[c]; emp[p] = 0;
+            out_next[rb + c] = GASM_NONE32; out_ov[rb + c] = 0;
+        }
+        __syncthreads();
+        u32 m = n;
+        bool bad = false;
+        for (int ov = k - 1; ov > 0 && !bad; --ov) {
+            if (!level_any[ov]) continue;            // nothing can merge at this overlap: the reference's pass changes nothing
+            const u8* M = match + (u64)ov * n * n;
+            const u8* RA = row_any + (u64)ov * n;
+            bool shrunk = true;
+            while (shrunk && !bad) {
+                const u32 before = m;
+                for (u32 i = 0; i < m && !bad; ++i) {
+                    if (emp[i]) continue;
+                    u32 ti = tail[i];
+                    if (!RA[ti]) continue;
+                    int jtop = (int)m - 1;
+                    while (jtop >= 0) {
+                        const int jj = jtop - (int)lane;
+                        const bool ok = jj >= 0 && jj != (int)i && !emp[jj] && M[(u64)ti * n + head[jj]];
+                        const unsigned long long mask = __ballot(ok);
+                        if (!mask) { jtop -= 64; continue; }
+                        const int j = jtop - (__ffsll((long long)mask) - 1);      // the highest matching position
+                        if (len[i] == len[j]) { bad = true; break; }              // c[i] == c[j] possible: the host's string test
+                        __syncthreads();                                          // (everybody has read the old state)
+                        if (lane == 0) {
+                            out_next[rb + ti] = head[j];
+                            out_ov[rb + ti] = (u8)ov;
+                            tail[i] = tail[j];
+                            len[i] += len[j] - (u32)ov;
+                            emp[j] = 1;
+                        }
+                        __syncthreads();
+                        ti = tail[i];
+                        if (!RA[ti]) break;           // the new tail matches nothing: the rest of the scan is idle
+                        jtop = j - 1;
+                    }
+                }
+                // order-preserving compaction of the chains that are left
+                u32 w = 0;
+                for (u32 base = 0; base < m; base += 64) {
+                    const u32 p = base + lane;
+                    const bool keep = p < m && !emp[p];
+                    const u32 h = keep ? head[p] : 0, t = keep ? tail[p] : 0, l = keep ? len[p] : 0;
+                    const unsigned long long mask = __ballot(keep);
+                    const u32 pos = w + (u32)__popcll(mask & ((1ull << lane) - 1ull));
+                    __syncthreads();
+                    if (keep) { head[pos] = h; tail[pos] = t; len[pos] = l; }
+                    w += (u32)__popcll(mask);
+                    __syncthreads();
+                }
+                for (u32 p = lane; p < w; p += 64) emp[p] = 0;
+                __syncthreads();
+                m = w;
+                shrunk = before != m;
+            }
+        }
+        for (u32 p = lane; p < m; p += 64) out_heads[rb + p] = head[p];
+        if (lane == 0) { out_nchains[r] = m; need_host[r] = bad ? 1 : 0; }
+        __syncthreads();
+    }
+}

@@ -155,6 +155,7 @@ int DevReads::upload(gasm_ctx* ctx, const char* reads, const u64* read_off, u64 
     const char* base = read_off ? reads + read_off[0] : reads;
     if (n && !reads && total_bases) { gasm_set_error("reads is null"); return GASM_ERR_INVALID; }
     DBuf ascii, err;
+    struct Rel { DBuf &a, &b; ~Rel() { a.release(); b.release(); } } rel{ascii, err};      // (also on the early returns below)
     GCHK(err.ensure(8));
     HIPCHK(hipMemsetAsync(err.p, 0, 8, ctx->stream));
     GCHK(h2d(ctx, ascii, base, total_bases));
@@ -933,6 +934,7 @@ int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 ta
     if (target_len >= 0xFFFFFF00ull) return GASM_OK;                       // host routine
     HIPCHK(hipSetDevice(ctx->device));
     DBuf ascii, err, twords, carry, d_out;
+    struct Rel { std::vector<DBuf*> v; ~Rel() { for (DBuf* b : v) b->release(); } } rel{{&ascii, &err, &twords, &carry, &d_out}};
     GCHK(err.ensure(8));
     HIPCHK(hipMemsetAsync(err.p, 0, 8, ctx->stream));
     GCHK(h2d(ctx, ascii, target, target_len));

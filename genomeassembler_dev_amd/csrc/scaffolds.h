@@ -10,5 +10,7 @@ struct gasm_scaffolds {
 };
 
 int scaffolds_from_signatures(gasm_ctx* ctx, const std::vector<std::string>& contigs, const std::vector<std::string>& sigs, gasm_scaffolds** out);
+int assemble_signatures_device(gasm_ctx* ctx, const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k,
+                               std::vector<std::string>& sigs, bool* used, u64* rows_on_host);
 int scaffolds_fetch(const gasm_scaffolds* sc, std::vector<char>& data, std::vector<u64>& off);
 int scaffolds_as_paths(const gasm_scaffolds* sc, DevPaths& dp);

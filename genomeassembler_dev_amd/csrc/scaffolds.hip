@@ -119,6 +119,92 @@ int scaffolds_from_signatures(gasm_ctx* ctx, const std::vector<std::string>& con
     return GASM_OK;
 }
 
+// The greedy merge of every permutation on the GPU (k_asm_match + k_asm_merge), its chains as sorted distinct signatures
+// (what gasm_host::assemble_signatures gives).  Permutations that ran into two chains of equal length (the reference's
+// full-string test) are redone by the host routine.  *used = false: the index form does not apply (host string form).
+int assemble_signatures_device(gasm_ctx* ctx, const std::vector<std::string>& contigs, const u32* perm, u64 rows, u64 row_len, int k,
+                               std::vector<std::string>& sigs, bool* used, u64* rows_on_host) {
+    *used = false;
+    if (rows_on_host) *rows_on_host = 0;
+    const u64 n = row_len;
+    size_t min_len = ~(size_t)0;
+    for (const std::string& s : contigs) min_len = std::min(min_len, s.size());
+    if (!(n > 0 && n == contigs.size() && k >= 2 && k <= 255 && min_len >= (size_t)(k - 1) && n <= 2048 && rows > 0)) return GASM_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    DBuf ascii, err, cwords, d_coff, d_clen, d_perm, d_match, d_ra, d_la, d_next, d_ov, d_heads, d_nch, d_need;
+    struct Rel { std::vector<DBuf*> v; ~Rel() { for (DBuf* b : v) b->release(); } } rel{{&ascii, &err, &cwords, &d_coff, &d_clen, &d_perm, &d_match, &d_ra, &d_la,
+                                                                                         &d_next, &d_ov, &d_heads, &d_nch, &d_need}};
+    std::vector<u64> coff(n + 1, 0);
+    std::vector<u32> clen(n);
+    std::string cat;
+    for (u64 i = 0; i < n; ++i) { cat += contigs[i]; coff[i + 1] = cat.size(); clen[i] = (u32)contigs[i].size(); }
+    GCHK(err.ensure(8));
+    HIPCHK(hipMemsetAsync(err.p, 0, 8, ctx->stream));
+    GCHK(up64(ctx, ascii, cat.data(), cat.size()));
+    const u64 nw = (cat.size() + 31) / 32;
+    GCHK(cwords.ensure((nw + 4) * 8));
+    GLAUNCH(ctx, "k_pack_ascii", k_pack_ascii, dim3(std::max(1u, std::min<u32>(ceil_div_u64(nw + 4, GASM_WG), (u32)ctx->n_cu * 32u))), dim3(GASM_WG), 0, ascii.as<u8>(),
+            (u64)cat.size(), (const u64*)nullptr, cwords.as<u64>(), err.as<u32>());
+    GCHK(up64(ctx, d_coff, coff.data(), coff.size() * 8));
+    GCHK(up64(ctx, d_clen, clen.data(), clen.size() * 4));
+    GCHK(up64(ctx, d_perm, perm, rows * n * 4));
+    const u64 msz = (u64)k * n * n;
+    GCHK(d_match.ensure(msz));
+    GCHK(d_ra.ensure((u64)k * n));
+    GCHK(d_la.ensure((u64)k + 8));
+    HIPCHK(hipMemsetAsync(d_ra.p, 0, (u64)k * n, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_la.p, 0, (u64)k + 8, ctx->stream));
+    GLAUNCH(ctx, "k_asm_match", k_asm_match, dim3(std::max(1u, std::min<u32>(ceil_div_u64((u64)(k - 1) * n * n, GASM_WG), (u32)ctx->n_cu * 64u))), dim3(GASM_WG), 0,
+            cwords.as<u64>(), d_coff.as<u64>(), (u32)n, k, d_match.as<u8>(), d_ra.as<u8>(), d_la.as<u8>());
+    GCHK(d_next.ensure(rows * n * 4));
+    GCHK(d_ov.ensure(rows * n));
+    GCHK(d_heads.ensure(rows * n * 4));
+    GCHK(d_nch.ensure(rows * 4));
+    GCHK(d_need.ensure(rows));
+    const size_t lds = (size_t)n * 13 + 16;
+    GLAUNCH(ctx, "k_asm_merge", k_asm_merge, dim3((u32)std::min<u64>(rows, (u64)ctx->n_cu * 32u)), dim3(64), lds, d_perm.as<u32>(), (u32)rows, (u32)n, k, d_clen.as<u32>(),
+            d_match.as<u8>(), d_ra.as<u8>(), d_la.as<u8>(), d_next.as<u32>(), d_ov.as<u8>(), d_heads.as<u32>(), d_nch.as<u32>(), d_need.as<u8>());
+    std::vector<u32> next(rows * n), heads(rows * n), nch(rows);
+    std::vector<u8> ov(rows * n), need(rows);
+    u32 herr = 0;
+    HIPCHK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(next.data(), d_next.p, rows * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ov.data(), d_ov.p, rows * n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(heads.data(), d_heads.p, rows * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(nch.data(), d_nch.p, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(need.data(), d_need.p, rows, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (herr) { gasm_set_error("contigs contain a base outside upper-case ACGT"); return GASM_ERR_NON_ACGT; }
+    // ---- chains -> signatures (u32 contig, u32 overlap, u32 contig, ...); rows the kernel handed back go to the host merge
+    std::vector<std::string> all;
+    std::vector<u32> redo;
+    std::string sig;
+    for (u64 r = 0; r < rows; ++r) {
+        if (need[r]) { redo.insert(redo.end(), perm + r * n, perm + (r + 1) * n); continue; }
+        for (u32 q = 0; q < nch[r]; ++q) {
+            sig.clear();
+            for (u32 x = heads[r * n + q];; x = next[r * n + x]) {
+                sig.append(reinterpret_cast<const char*>(&x), 4);
+                if (next[r * n + x] == GASM_NONE32) break;
+                const u32 o = ov[r * n + x];
+                sig.append(reinterpret_cast<const char*>(&o), 4);
+            }
+            all.push_back(sig);
+        }
+    }
+    if (!redo.empty()) {
+        std::vector<std::string> hs;
+        if (!gasm_host::assemble_signatures(contigs, redo.data(), redo.size() / n, n, k, hs)) return GASM_OK;      // (cannot happen: same preconditions)
+        all.insert(all.end(), hs.begin(), hs.end());
+        if (rows_on_host) *rows_on_host = redo.size() / n;
+    }
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    sigs.swap(all);
+    *used = true;
+    return GASM_OK;
+}
+
 int scaffolds_fetch(const gasm_scaffolds* sc, std::vector<char>& data, std::vector<u64>& off) {
     gasm_ctx* ctx = sc->ctx;
     HIPCHK(hipSetDevice(ctx->device));

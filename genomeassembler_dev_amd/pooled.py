@@ -61,13 +61,16 @@ class VirtualComm:
 class DistComm:
     """one rank per process over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" on the CPU)"""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, stage_on_host=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.local_ranks = [self.rank]
+        # gloo moves host memory: device buffers are staged through the host (rehearsals of the multi-rank flow on a box
+        # without RCCL peers); with "nccl" the device buffers go as they are
+        self.stage = (dist.get_backend(group) == "gloo") if stage_on_host is None else stage_on_host
 
     def all_to_all(self, sends, recv_sizes):
         """sends[rank] = list of `world` 1-D tensors; recv_sizes[rank] = list of `world` element counts"""
@@ -77,8 +80,14 @@ class DistComm:
         sizes_out = [int(n) for n in recv_sizes[self.rank]]
         ref = send[0]
         inp = torch.cat([t.reshape(-1) for t in send]) if sum(sizes_in) else ref.new_empty(0)
-        out = ref.new_empty(sum(sizes_out))
-        self.dist.all_to_all_single(out, inp, output_split_sizes=sizes_out, input_split_sizes=sizes_in, group=self.group)
+        if self.stage and inp.is_cuda:
+            h_in = inp.cpu()
+            h_out = h_in.new_empty(sum(sizes_out))
+            self.dist.all_to_all_single(h_out, h_in, output_split_sizes=sizes_out, input_split_sizes=sizes_in, group=self.group)
+            out = h_out.to(ref.device)
+        else:
+            out = ref.new_empty(sum(sizes_out))
+            self.dist.all_to_all_single(out, inp, output_split_sizes=sizes_out, input_split_sizes=sizes_in, group=self.group)
         return {self.rank: list(torch.split(out, sizes_out))}
 
     def barrier(self):

@@ -69,7 +69,8 @@ def test_get_contigs_reference_operating_points(read_len, k):
     # distinct k-mers are the distinct edges: (prefix, suffix) lists must agree too
     assert [d[:-1] for d in m.distinct_kmers()] == ref["edge_prefix"]
     assert [d[1:] for d in m.distinct_kmers()] == ref["edge_suffix"]
-    assert ga.assemble_contigs(m, k) == orc.assemble_contigs(ref["contigs"], ref["perm"], k)
+    assert ga.assemble_contigs(m, k, ctx=ga.default_context()) == orc.assemble_contigs(ref["contigs"], ref["perm"], k)     # merge on the GPU
+    assert ga.assemble_contigs(m, k) == orc.assemble_contigs(ref["contigs"], ref["perm"], k)                                 # host merge (no context)
 
 
 @pytest.mark.parametrize("k", [2, 3, 5, 11, 21, 31, 32, 33, 41, 51, 63])
@@ -387,7 +388,7 @@ def _score_case(seed, L=1200, rl=20, cov=40, k=15):
     reads = _strs(synth.simulate_reads(g, rl, cov, seed + 1))
     km = ga.get_kmers_from_reads(reads, k)
     m = ga.get_contigs(km, k, 1234, matrix_rows=200)
-    return g.tobytes().decode(), reads, ga.assemble_contigs(m, k)
+    return g.tobytes().decode(), reads, ga.assemble_contigs(m, k, ctx=ga.default_context())
 
 
 def test_calc_breakscore_own_variant(qtable):
@@ -655,7 +656,7 @@ def test_read_simulator_against_oracle(qtable):
     b.close()
 
 
-def test_device_resident_scaffolds(qtable):
+def test_device_resident_scaffolds(qtable, monkeypatch):
     """assemble_contigs with the result left on the GPU (chains expanded to 2-bit, ordered and de-duplicated as strings
     there) and calc_breakscore fed from the handle: the scaffold list, its order and every score equal the oracle's; the
     string form of the same call goes through the same device route when it is given a context"""
@@ -672,6 +673,9 @@ def test_device_resident_scaffolds(qtable):
         assert len(sc) == len(ref) and sc.lengths.tolist() == [len(s) for s in ref]
         assert sc.strings() == ref
         assert ga.assemble_contigs(m, k, ctx=ga.default_context()) == ref
+        monkeypatch.setenv("GASM_ASM_HOST_MERGE", "1")          # same scaffolds with the merge on host threads
+        assert ga.assemble_contigs(m, k, ctx=ga.default_context()) == ref
+        monkeypatch.delenv("GASM_ASM_HOST_MERGE")
         for variant in ("own", "velvet"):
             mine = ga.calc_breakscore(sc, reads, truth, 8, keys, prob, variant=variant, with_lev=True, with_freq=False, with_ks=(variant == "own"))
             o = orc.calc_breakscore(ref, reads, truth, 8, keys, prob, velvet=(variant == "velvet"), with_lev=True, with_freq=(variant == "own"))
