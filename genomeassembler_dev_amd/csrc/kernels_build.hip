@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(64) k_seg_offsets(const u32* __restrict__ seg_
 // words) are requested BEFORE the flush, and the flush issues exactly NFL stores per thread whatever the tile holds
 // (lanes past the end write to a per-wave scratch line): the wait at the top of the next tile is then "all but the
 // last NFL operations", written out explicitly.
-// LDS: NFL * 512 keys (72 KB) + nb * 12 + 64 -> two workgroups per CU.
+// LDS: NFL * 512 x 16 bytes (72 KB) + 64 trash slots + nb * 24 + 96 -> two workgroups per CU, for both key widths.
 // ================================================================================================================
 template <class K> struct TilePrefetch {
     Roll<K> rl;
@@ -303,8 +303,8 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
     constexpr u32 CAP = NFL * GASM_TILE_WG * KPU;
     const u32 nb = 1u << bbits;
     const u32 tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, sub = tid & 3u;
-    K* s_key = reinterpret_cast<K*>(s_raw);                                  // CAP + one trash slot per thread
-    u64* s_comb = reinterpret_cast<u64*>(s_key + CAP + GASM_TILE_WG);        // nb
+    K* s_key = reinterpret_cast<K*>(s_raw);                                  // CAP + eight trash slots per wave
+    u64* s_comb = reinterpret_cast<u64*>(s_key + CAP + GASM_TILE_WG / 8);    // nb
     u32* s_cur = reinterpret_cast<u32*>(s_comb + ((nb + 1) & ~1u));          // 4 per bucket (sub-cursors) + dummy bin; 16-byte aligned
     u32* s_tmp = s_cur + 4 * nb + 4;                                         // 12
     const int bshift = 2 * k - bbits;
@@ -376,9 +376,11 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
         const u32 tnext = tile + 1 < tile_end ? tile + 1 : tile;
         const TileInfo tin = tile_decode(tinfo, tnext);
         fetch(tnext, tin, pf);
-        // (a start past the end of the read goes to the thread's trash slot: cheaper than a branch per k-mer)
+        // (a start past the end of the read goes to a trash slot: cheaper than a branch per k-mer.  Eight slots per wave,
+        // not one per thread: with 128-bit keys the per-thread slots were the 8 KB that kept a second workgroup off the CU)
+        const u32 trash = CAP + wv * 8 + (ln & 7u);
 #pragma unroll
-        for (u32 j = 0; j < KT; ++j) s_key[j < nv ? idx[j] : CAP + tid] = key[j];
+        for (u32 j = 0; j < KT; ++j) s_key[j < nv ? idx[j] : trash] = key[j];
         __syncthreads();
         // ---- stream out: NFL 16-byte stores per thread (a pair of 64-bit keys or one 128-bit key; staged runs are even,
         // so a pair never straddles two buckets), three at a time so that their LDS reads overlap
@@ -512,6 +514,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     const u32 bucket = blockIdx.x;
     const u64 beg = bstart[bucket], end = bstart[bucket + 1];
     const u64 n = end - beg;
+    const u32 warm = (u32)(dbg >> 2) & 3u;        // iterations taken key by key (64-bit keys)
     for (u32 i = threadIdx.x; i < TBL; i += GASM_WG) { t_key[i] = key_empty<K>(); t_cnt[i] = 0; }
     for (u32 i = threadIdx.x; i < BINS; i += GASM_WG) s_start[i] = 0;
     if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }  // [4] distinct so far, [5] overflow, [6] longest bin
@@ -544,6 +547,22 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
         if ((dbg & 3) == 1) { u64 x = 0; for (int q = 0; q < KPL; ++q) x ^= khash(kx[q]); if (x == 0x1234567) s_tmp[6] = 1; continue; }
         if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { s_tmp[5] = 1; break; }
         if constexpr (!WIDE) {
+            // While the table fills (the first `warm` iterations: 2048 keys each, ~600 distinct per bucket) nearly every
+            // key misses its home set, and the batched form below would send all eight keys of every lane through the slow
+            // loop — 17 of a workgroup's 95 us (GASM_DBG_STAMPS).  There the keys are taken one after the other instead:
+            // a key inserted by any lane at step q is a plain hit for everybody from step q + 1 on.
+            if (c < (u64)warm * 4 * GASM_WG) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const u64 key = kx[q];
+                    if (kis_filler(key)) continue;
+                    u32 st = khash(key) >> (32 - LOG_SETS);
+                    bool ok = false;
+                    for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
+                    if (!ok) s_tmp[5] = 1;
+                }
+                continue;
+            }
             // two batches of four keys: the four home sets are read together (8 x ds_read_b128 in flight) and hits are
             // counted.  Keys that miss their home set (new keys, and the ~1.5 % whose home set has overflowed) are only
             // noted: with 64 lanes some lane misses for almost every key index, and handling misses in place ran the

@@ -34,6 +34,7 @@ __global__ void k_add_empty_reads(PathSet ps, const u64* __restrict__ seg_empty,
 struct Knobs {
     int dedup_tbl = 0, dbg_dedup = 0, padm = -1, scatter_wgs = 8, hist_wgs = 64, rank_rounds = 18, bbits_add = 0, ruler_shift = 0;
     bool rank_global = false, sync_build = false;
+    int dedup_warm = 0;
     const char* stamps = nullptr;
     Knobs() {
         if (const char* v = getenv("GASM_DEDUP_TBL")) dedup_tbl = atoi(v);
@@ -46,6 +47,7 @@ struct Knobs {
         if (const char* v = getenv("GASM_DBG_RANK_ROUNDS")) rank_rounds = atoi(v);
         rank_global = getenv("GASM_RANK_GLOBAL") != nullptr;
         sync_build = getenv("GASM_SYNC_BUILD") != nullptr;       // wait for every build's report at once (diagnostic)
+        if (const char* v = getenv("GASM_DEDUP_WARM")) dedup_warm = std::max(0, std::min(3, atoi(v)));     // first iterations of the 64-bit de-duplication taken key by key
         stamps = getenv("GASM_DBG_STAMPS");
     }
 };
@@ -471,7 +473,7 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
     GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S, std::max(1u, nb / 32u)), dim3(1024), 0, rs, bbits, padm, bs.d_tcnt.as<ushort4>(),
             bs.d_toff.as<u32>(), bs.d_hist.as<u32>());
     GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
-    const size_t lds = (size_t)((W == 1 ? 18 : 9) + 1) * GASM_TILE_WG * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
+    const size_t lds = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (GASM_TILE_WG / 8) * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
     // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
     const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
     if (W == 1) {
@@ -493,7 +495,7 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
         HIPCHK(hipMemsetAsync(stamp_buf.p, 0, 64 + (size_t)nbt * 24, ctx->stream));
         d_stamps = stamp_buf.as<unsigned long long>();
     }
-    const int dbg_d = knobs().dbg_dedup;
+    const int dbg_d = knobs().dbg_dedup | (knobs().dedup_warm << 2);
     bs.fbits = bs.small_tbl ? 9 : 10;   // bins of the de-duplication kernel's counting sort = TBL / 4
     GCHK(bs.d_fdir.ensure((size_t)nbt * ((1u << bs.fbits) + 1) * 2));
     // (k_bucket_dedup writes every entry of its bucket's fine directory)
