@@ -98,6 +98,31 @@ k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, co
     __shared__ u32 s_cur[BINS];
     __shared__ u32 s_tmp[8];
     const u32 j = blockIdx.x;
+    // ---- a bucket with a single source run (every bucket of the second exchange; all of them with one rank) is sorted and
+    // distinct already: copy it and build its fine directory by searching the bin boundaries
+    {
+        u32 n_nonempty = 0, only = 0;
+        for (u32 s = 0; s < n_src; ++s) if (run_len[(u64)j * n_src + s]) { ++n_nonempty; only = s; }
+        if (n_nonempty <= 1) {
+            const u32 len = n_nonempty ? run_len[(u64)j * n_src + only] : 0u;
+            const u64 off = n_nonempty ? run_off[(u64)j * n_src + only] : 0ull;
+            if (len > (u32)LIMIT) { if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[j] = 0; } return; }
+            const u64 beg = bstart[j];
+            for (u32 i = threadIdx.x; i < len; i += GASM_WG) { out_keys[beg + i] = in_keys[off + i]; out_cnt[beg + i] = in_cnt[off + i]; }
+            constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
+            const int bshift = low_bits > (LOG_TBL - 2) ? low_bits - (LOG_TBL - 2) : 0;
+            for (u32 b = threadIdx.x; b <= (u32)BINS; b += GASM_WG) {
+                u32 lo = 0, hi = len;                       // first record whose bin is >= b (bins ascend along a sorted run)
+                while (lo < hi) {
+                    const u32 m = (lo + hi) >> 1;
+                    if ((kfield(in_keys[off + m], bshift) & (u32)(BINS - 1)) < b) lo = m + 1; else hi = m;
+                }
+                fdir[(u64)j * (BINS + 1) + b] = (u16)(b == (u32)BINS ? len : lo);
+            }
+            if (threadIdx.x == 0) bucket_d[j] = len;
+            return;
+        }
+    }
     for (u32 i = threadIdx.x; i < TBL; i += GASM_WG) { t_key[i] = key_empty<K>(); t_cnt[i] = 0; }
     for (u32 i = threadIdx.x; i < BINS; i += GASM_WG) s_start[i] = 0;
     if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }
