@@ -75,6 +75,9 @@ SYMBOLS = {
     "gasm_batch_create": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _u32, _PP]),
     "gasm_batch_create_packed": (_int, [_vp, _vp, _vp, _u64, _u32, _vp, _u32, _PP]),
     "gasm_batch_from_files": (_int, [_vp, _vp, _u32, _int, _PP, C.POINTER(_u64)]),
+    "gasm_batch_guided": (_int, [_vp]),
+    "gasm_batch_fetch_guided": (_int, [_vp, _PP, _PP, _PP, _PP, _PP, _PP]),
+    "gasm_batch_fetch_score_fixed": (_int, [_vp, _PP, C.POINTER(_int)]),
     "gasm_batch_simulate": (_int, [_vp, _vp, _vp, _u32, _u32, C.c_double, _u64, _int, _vp, _PP]),
     "gasm_batch_fetch_read_starts": (_int, [_vp, _PP, _PP]),
     "gasm_read_files": (_int, [_vp, _u32, _int, _PP]),

@@ -164,6 +164,30 @@ class SegmentBatch:
                     bp_score_norm_by_len=arr(ps[2], C.c_double), kmer_breaks=arr(ps[3], C.c_int32),
                     sequence_len=arr(ps[4], C.c_int32), seg_contig_off=seg)
 
+    def score_fixed(self):
+        """(int64 fixed-point breakage sums per contig, shift): bp_score == fx * 2**-shift exactly"""
+        p, sh = C.c_void_p(), C.c_int()
+        check(lib().gasm_batch_fetch_score_fixed(self.h, C.byref(p), C.byref(sh)))
+        seg, _, _ = self.contigs_raw()
+        n = int(seg[-1])
+        fx = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int64)), shape=(n,)).copy() if n else np.zeros(0, np.int64)
+        return fx, sh.value
+
+    def guided(self):
+        """breakage-score-guided scaffolds (not in the reference) of a built + scored batch:
+        list per segment of dicts(sequence, bp_score, bp_score_norm_by_len, kmer_breaks), longest first"""
+        check(lib().gasm_batch_guided(self.h))
+        ps = [C.c_void_p() for _ in range(6)]
+        check(lib().gasm_batch_fetch_guided(self.h, *[C.byref(p) for p in ps]))
+        seg = np.ctypeslib.as_array(C.cast(ps[0], C.POINTER(C.c_uint64)), shape=(self.n_segments + 1,)).copy()
+        n = int(seg[-1])
+        off = np.ctypeslib.as_array(C.cast(ps[1], C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+        raw = C.string_at(ps[2], int(off[-1])) if n and off[-1] else b""
+        arr = lambda p, ct: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(n,)).copy() if n else np.zeros(0, ct)
+        bp, nl, br = arr(ps[3], C.c_double), arr(ps[4], C.c_double), arr(ps[5], C.c_int32)
+        return [[dict(sequence=raw[int(off[i]):int(off[i + 1])].decode(), bp_score=bp[i], bp_score_norm_by_len=nl[i], kmer_breaks=int(br[i]))
+                 for i in range(int(seg[s]), int(seg[s + 1]))] for s in range(self.n_segments)]
+
     def close(self):
         if self.h:
             lib().gasm_batch_free(self.h)

@@ -53,6 +53,7 @@ struct SubBatch {
     ScoreState ss;
     bool paths_ready = false, table_set = false;
     hipEvent_t ev_streamed = nullptr;
+    GuidedState guided;
 };
 
 struct gasm_batch {
@@ -75,6 +76,7 @@ struct gasm_batch {
     // simulated batches: the start of every read in its genome
     DBuf d_read_start;
     std::vector<u32> h_read_start;
+    std::vector<int64_t> h_fx;
     std::vector<u64> h_sim_seg_off;
 };
 
@@ -652,7 +654,7 @@ void gasm_batch_free(gasm_batch* b) {
     b->d_read_start.release();
     for (SubBatch& sb : b->sub) {
         if (sb.cx) { (void)hipSetDevice(sb.cx->device); (void)hipStreamSynchronize(sb.cx->stream); }
-        sb.rd.release(); sb.bs.release(); sb.dp.release(); sb.tb.release(); sb.ss.release();
+        sb.rd.release(); sb.bs.release(); sb.dp.release(); sb.tb.release(); sb.ss.release(); sb.guided.release();
         if (sb.ev_streamed) (void)hipEventDestroy(sb.ev_streamed);
     }
     delete b;
@@ -697,6 +699,53 @@ int gasm_batch_score(gasm_batch* b, int kmer, const double* table) {
     }
     b->scored = true;
     b->score_kmer = kmer;
+    return GASM_OK;
+    API_GUARD_END
+}
+
+// ---- row A16: breakage-score-guided traversal of a built + scored batch
+int gasm_batch_guided(gasm_batch* b) {
+    API_GUARD_BEGIN
+    if (!b) { gasm_set_error("batch is null"); return GASM_ERR_INVALID; }
+    if (!b->built || !b->scored) { gasm_set_error("gasm_batch_guided needs gasm_batch_build and gasm_batch_score first"); return GASM_ERR_STATE; }
+    if (b->sub.size() != 1) { gasm_set_error("gasm_batch_guided: batches split into sub-batches are not supported"); return GASM_ERR_STATE; }
+    GCHK(batch_finish(b));
+    SubBatch& sb = b->sub[0];
+    GCHK(pipeline_score_fetch(sb.cx, sb.ss));
+    return guided_build(sb.cx, sb.rd, sb.bs, sb.dp, sb.ss, sb.tb, b->score_kmer, sb.guided);
+    API_GUARD_END
+}
+
+int gasm_batch_fetch_guided(gasm_batch* b, const uint64_t** seg_off, const uint64_t** off, const char** data, const double** bp_score,
+                            const double** norm_by_len, const int32_t** kmer_breaks) {
+    API_GUARD_BEGIN
+    if (!b || !seg_off || !off || !data || !bp_score || !norm_by_len || !kmer_breaks) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
+    if (b->sub.size() != 1 || !b->sub[0].guided.valid) { gasm_set_error("fetch before gasm_batch_guided"); return GASM_ERR_STATE; }
+    GuidedState& g = b->sub[0].guided;
+    GCHK(guided_fetch_text(b->sub[0].cx, g));
+    *seg_off = g.h_seg_off.data(); *off = g.h_text_off.data(); *data = g.h_text.data();
+    *bp_score = g.ss.h_bp.data(); *norm_by_len = g.ss.h_nl.data(); *kmer_breaks = g.ss.h_breaks.data();
+    return GASM_OK;
+    API_GUARD_END
+}
+
+// the fixed-point breakage sums behind the last gasm_batch_score: bp_score[c] = fx[c] * 2^-shift exactly (what the guided
+// traversal compares, and what its CPU restatement recomputes)
+int gasm_batch_fetch_score_fixed(gasm_batch* b, const int64_t** fx, int* shift) {
+    API_GUARD_BEGIN
+    if (!b || !fx || !shift) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
+    if (b->sub.size() != 1 || !b->scored) { gasm_set_error("gasm_batch_fetch_score_fixed needs a scored, unsplit batch"); return GASM_ERR_STATE; }
+    GCHK(batch_finish(b));
+    SubBatch& sb = b->sub[0];
+    if (!sb.ss.graph) { gasm_set_error("the batch was not scored through its graph"); return GASM_ERR_STATE; }
+    const u32 P = sb.bs.n_contigs;
+    b->h_fx.resize(P);
+    const size_t fx_off = (sb.ss.stride * 4 + 15) & ~(size_t)15;
+    HIPCHK(hipSetDevice(sb.cx->device));
+    if (P) HIPCHK(hipMemcpyAsync(b->h_fx.data(), static_cast<const char*>(sb.ss.d_total.p) + fx_off, (size_t)P * 8, hipMemcpyDeviceToHost, sb.cx->stream));
+    HIPCHK(hipStreamSynchronize(sb.cx->stream));
+    *fx = b->h_fx.data();
+    *shift = sb.tb.fix_shift;
     return GASM_OK;
     API_GUARD_END
 }

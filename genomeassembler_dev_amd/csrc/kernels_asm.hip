@@ -188,3 +188,88 @@ __global__ void __launch_bounds__(64) k_asm_merge(const u32* __restrict__ perm, 
         __syncthreads();
     }
 }
+
+// ================================================================================================================
+// Row A16 — breakage-score-guided traversal (BASELINE configs[4]'s "combined" mode).  The reference does not have it
+// (README.md:83); the specification is this project's, restated on the CPU by oracle/guided_oracle.py:
+// contigs end at branching nodes; the guided traversal chains them through those nodes, steered by the breakage score:
+//   score of a contig = its fixed-point breakage sum / its length, compared as an exact rational (cross-multiplied in 128
+//   bits: no rounding, so the CPU restatement makes the same choices);
+//   seeds in order of descending score (ties: smaller contig index = lexicographically smaller contig); a seed is
+//   extended to the right — among the unused contigs whose first k-1 bases are the path's last k-1 bases the best-scoring
+//   one, again and again — then to the left the same way; every contig ends up in exactly one guided scaffold.
+// One wave per segment; candidates are examined 64 at a time, the best found by a butterfly reduction.
+// ================================================================================================================
+struct GBest { unsigned long long fs; u32 len; u32 idx; };
+__device__ __forceinline__ bool gbest_better(const GBest& a, const GBest& b) {          // a before b?
+    if (b.idx == GASM_NONE32) return a.idx != GASM_NONE32;
+    if (a.idx == GASM_NONE32) return false;
+    // a.fs / a.len > b.fs / b.len  <=>  a.fs * b.len > b.fs * a.len   (128-bit products)
+    const unsigned long long al = a.fs * (unsigned long long)b.len, ah = __umul64hi(a.fs, (unsigned long long)b.len);
+    const unsigned long long bl = b.fs * (unsigned long long)a.len, bh = __umul64hi(b.fs, (unsigned long long)a.len);
+    if (ah != bh) return ah > bh;
+    if (al != bl) return al > bl;
+    return a.idx < b.idx;
+}
+__device__ __forceinline__ GBest gbest_wave(GBest v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        GBest o;
+        o.fs = __shfl_xor(v.fs, d, 64); o.len = __shfl_xor(v.len, d, 64); o.idx = __shfl_xor(v.idx, d, 64);
+        if (gbest_better(o, v)) v = o;
+    }
+    return v;
+}
+// the k1 bases at p and at q equal?  (k1 <= 62)
+__device__ __forceinline__ bool bases_eq_short(const u64* __restrict__ w, u64 p, u64 q, int k1) {
+    for (int o = 0; o < k1; o += 32) {
+        u64 a = window32(w, p + o), b = window32(w, q + o);
+        const int left = k1 - o;
+        if (left < 32) { const u64 mk = ~0ull << (64 - 2 * left); a &= mk; b &= mk; }
+        if (a != b) return false;
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(64) k_guided_chain(PathSet ps, const unsigned long long* __restrict__ fx, int k, u32* __restrict__ g_next,
+                                                     u32* __restrict__ g_prev) {
+    extern __shared__ u8 s_used[];
+    const u32 seg = blockIdx.x, lane = threadIdx.x;
+    const u32 c0 = ps.seg_path_off[seg], n = ps.seg_path_off[seg + 1] - c0;
+    for (u32 i = lane; i < n; i += 64) { s_used[i] = 0; g_next[c0 + i] = GASM_NONE32; g_prev[c0 + i] = GASM_NONE32; }
+    __syncthreads();
+    const int k1 = k - 1;
+    auto best_of = [&](int mode, u32 cur) {      // mode 0: any unused; 1: unused that can follow cur; 2: unused that cur can follow
+        GBest b{0ull, 1u, GASM_NONE32};
+        const u64 cb = mode ? ps.p_off[c0 + cur] : 0, ce = mode ? ps.p_off[c0 + cur + 1] : 0;
+        for (u32 j = lane; j < n; j += 64) {
+            if (s_used[j]) continue;
+            const u64 jb = ps.p_off[c0 + j], je = ps.p_off[c0 + j + 1];
+            if (mode == 1 && !bases_eq_short(ps.words, ce - k1, jb, k1)) continue;
+            if (mode == 2 && !bases_eq_short(ps.words, je - k1, cb, k1)) continue;
+            const GBest c{fx[c0 + j], (u32)(je - jb), j};
+            if (gbest_better(c, b)) b = c;
+        }
+        return gbest_wave(b);
+    };
+    for (;;) {
+        const GBest seed = best_of(0, 0);
+        if (seed.idx == GASM_NONE32) break;
+        if (lane == 0) s_used[seed.idx] = 1;
+        __syncthreads();
+        for (int dir = 1; dir <= 2; ++dir) {
+            u32 cur = seed.idx;
+            for (;;) {
+                const GBest nx = best_of(dir, cur);
+                if (nx.idx == GASM_NONE32) break;
+                if (lane == 0) {
+                    s_used[nx.idx] = 1;
+                    if (dir == 1) { g_next[c0 + cur] = c0 + nx.idx; g_prev[c0 + nx.idx] = c0 + cur; }
+                    else { g_next[c0 + nx.idx] = c0 + cur; g_prev[c0 + cur] = c0 + nx.idx; }
+                }
+                __syncthreads();
+                cur = nx.idx;
+            }
+        }
+    }
+}

@@ -238,3 +238,88 @@ int scaffolds_as_paths(const gasm_scaffolds* sc, DevPaths& dp) {
     HIPCHK(hipMemcpyAsync(dp.d_words.p, sc->d_words.p, nw * 8, hipMemcpyDeviceToDevice, ctx->stream));
     return dp.upload_dirs(ctx);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Row A16: breakage-score-guided traversal (kernels_asm.hip, k_guided_chain; specification in DESIGN.md §8)
+// ---------------------------------------------------------------------------------------------------------------
+int guided_build(gasm_ctx* ctx, DevReads& rd, BuildState& bs, DevPaths& cp, ScoreState& cs, const ScoreTable& tb, int kmer, GuidedState& g) {
+    g.valid = false;
+    if (!cs.graph || cs.graph != &bs) { gasm_set_error("guided traversal needs the batch scored through its graph (reads of at least k bases)"); return GASM_ERR_STATE; }
+    if (rd.n_empty) { gasm_set_error("guided traversal: empty reads are not supported"); return GASM_ERR_INVALID; }
+    HIPCHK(hipSetDevice(ctx->device));
+    const u32 S = rd.n_segments, P = bs.n_contigs;
+    const int k = bs.k;
+    u32 max_c = 1;
+    for (u32 s = 0; s < S; ++s) max_c = std::max(max_c, bs.h_seg_cstart[s + 1] - bs.h_seg_cstart[s]);
+    if (max_c > 60000) { gasm_set_error("guided traversal: more than 60000 contigs in a segment"); return GASM_ERR_CAPACITY; }
+    DBuf d_next, d_prev, tmp[5];
+    struct Rel { std::vector<DBuf*> v; ~Rel() { for (DBuf* b : v) b->release(); } } rel{{&d_next, &d_prev, &tmp[0], &tmp[1], &tmp[2], &tmp[3], &tmp[4]}};
+    GCHK(d_next.ensure(std::max<u32>(P, 1) * 4));
+    GCHK(d_prev.ensure(std::max<u32>(P, 1) * 4));
+    const size_t fx_off = (cs.stride * 4 + 15) & ~(size_t)15;
+    const unsigned long long* d_fx = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(cs.d_total.p) + fx_off);
+    GLAUNCH(ctx, "k_guided_chain", k_guided_chain, dim3(S), dim3(64), (size_t)max_c + 16, cp.view(), d_fx, k, d_next.as<u32>(), d_prev.as<u32>());
+    std::vector<u32> next(P), prev(P);
+    if (P) {
+        HIPCHK(hipMemcpyAsync(next.data(), d_next.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(prev.data(), d_prev.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // ---- chains -> scaffolds, per segment by descending length, ties by first contig (= lexicographic: contigs are sorted
+    // and begin with distinct k-mers)
+    std::vector<u64> clen(P);
+    GCHK(pipeline_fetch_contigs(ctx, rd, bs));
+    for (u32 c = 0; c < P; ++c) clen[c] = bs.h_c_off[c + 1] - bs.h_c_off[c];
+    ChainCsr csr;
+    csr.clear();
+    g.h_seg_off.assign((size_t)S + 1, 0);
+    struct Ch { u64 len; u32 head; };
+    for (u32 s = 0; s < S; ++s) {
+        std::vector<Ch> chains;
+        for (u32 c = bs.h_seg_cstart[s]; c < bs.h_seg_cstart[s + 1]; ++c) {
+            if (prev[c] != GASM_NONE32) continue;
+            u64 len = clen[c];
+            for (u32 x = c; next[x] != GASM_NONE32; x = next[x]) len += clen[next[x]] - (u64)(k - 1);
+            chains.push_back(Ch{len, c});
+        }
+        std::stable_sort(chains.begin(), chains.end(), [](const Ch& a, const Ch& b) { return a.len > b.len; });      // heads ascend inside equal lengths
+        for (const Ch& ch : chains) {
+            u64 pos = 0;
+            csr.elem_contig.push_back(ch.head); csr.elem_skip.push_back(0); csr.elem_pos.push_back(0);
+            pos += clen[ch.head];
+            for (u32 x = ch.head; next[x] != GASM_NONE32; x = next[x]) {
+                csr.elem_contig.push_back(next[x]); csr.elem_skip.push_back((u32)(k - 1)); csr.elem_pos.push_back(pos);
+                pos += clen[next[x]] - (u64)(k - 1);
+            }
+            csr.sig_off.push_back(csr.elem_contig.size());
+            csr.out_off.push_back(csr.out_off.back() + pos);
+        }
+        g.h_seg_off[s + 1] = csr.sig_off.size() - 1;
+    }
+    const u32 G = (u32)(csr.sig_off.size() - 1);
+    DevPaths& dp = g.dp;
+    dp.n_segments = S; dp.n_paths = G;
+    dp.b_p_off = nullptr; dp.b_seg_path_off = nullptr; dp.b_seg_base_off = nullptr;
+    dp.h_p_off = csr.out_off;
+    dp.total_bases = csr.out_off[G];
+    if (dp.total_bases >= 0xFFFFFFF0ull) { gasm_set_error("guided scaffolds exceed 2^32 bases"); return GASM_ERR_CAPACITY; }
+    dp.h_seg_path_off.assign((size_t)S + 1, 0);
+    for (u32 s = 0; s <= S; ++s) dp.h_seg_path_off[s] = (u32)g.h_seg_off[s];
+    // contigs are packed already (the scorer's copy) with their offsets on the device
+    GCHK(expand(ctx, csr, cp.d_words.as<u64>(), bs.d_c_off.as<u64>(), dp.d_words, tmp));
+    GCHK(dp.upload_dirs(ctx));
+    GCHK(pipeline_score_launch(ctx, rd, dp, kmer, tb, false, false, g.ss, nullptr));
+    GCHK(pipeline_score_fetch(ctx, g.ss));
+    g.h_text.clear(); g.h_text_off.clear();
+    g.valid = true;
+    return GASM_OK;
+}
+
+int guided_fetch_text(gasm_ctx* ctx, GuidedState& g) {
+    if (!g.h_text_off.empty()) return GASM_OK;
+    gasm_scaffolds view;
+    view.ctx = ctx; view.n = g.dp.n_paths; view.h_off = g.dp.h_p_off; view.d_words = g.dp.d_words;      // (borrowed)
+    const int st = scaffolds_fetch(&view, g.h_text, g.h_text_off);
+    view.d_words = DBuf();
+    return st;
+}

@@ -279,6 +279,20 @@ int gasm_pool_fetch_contigs(gasm_pool* p, const uint64_t** seg_contig_off, const
 int gasm_pool_fetch_scores(gasm_pool* p, const double** bp_score, const double** norm_by_break_freqs, const double** norm_by_len,
                            const int32_t** kmer_breaks, const int32_t** sequence_len);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Breakage-score-guided traversal (BASELINE configs[4]'s "combined" mode).  NOT in the reference
+ * (README.md:83 "out of scope"): specified by this project, parity = agreement with the project's own CPU
+ * restatement (oracle/guided_oracle.py).  Contigs end at branching nodes; guided scaffolds chain them through those nodes:
+ * seeds by descending breakage score per base (exact rational of the fixed-point sums), each extended to the right, then to
+ * the left, by the best-scoring unused contig that overlaps by k-1 bases; every contig is used once.  Call after
+ * gasm_batch_build + gasm_batch_score.  fetch: scaffolds per segment (longest first), their text and scores.
+ * ---------------------------------------------------------------------------------------------------------------- */
+int gasm_batch_guided(gasm_batch* b);
+int gasm_batch_fetch_guided(gasm_batch* b, const uint64_t** seg_off /*n_segments+1*/, const uint64_t** off, const char** data,
+                            const double** bp_score, const double** norm_by_len, const int32_t** kmer_breaks);
+/* the exact fixed-point sums behind the batch scores: bp_score[c] == fx[c] * 2^-shift */
+int gasm_batch_fetch_score_fixed(gasm_batch* b, const int64_t** fx, int* shift);
+
 /* Per-kernel device time of the stages of build/score, accumulated with HIP events on the ctx stream since the last
  * reset (profiling on costs one event pair per launch).  names/ms/launches point into library storage. */
 int gasm_profile_enable(gasm_ctx* ctx, int on);

@@ -704,3 +704,41 @@ def test_device_resident_scaffolds(qtable, monkeypatch):
         sc = ga.assemble_contigs_velvet(short, 4, 2, rows=40, on_device=True)
         assert sc.strings() == ref
         sc.close()
+
+
+def test_guided_traversal_against_own_restatement(qtable):
+    """SURVEY §8 row A16 (configs[4]'s "combined" mode).  Not in the reference: gasm_batch_guided is checked against
+    oracle/guided_oracle.py, the CPU restatement of this project's own specification — the fixed-point sums it steers by
+    are recomputed there read by read, the guided scaffolds must be the same strings in the same order, and their scores
+    equal the oracle scorer's on those strings.  64- and 128-bit keys, several segments, a segment without branching."""
+    from oracle import guided_oracle
+    keys, prob = qtable
+    table = dict(zip(keys, prob.tolist()))
+    for k, rl, n_seg, L in ((15, 30, 4, 2500), (41, 70, 3, 4000)):
+        reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, 30, seed0=9500 + k, planted=True)
+        plain = synth.make_segment(77, 1500, planted=False)                      # a segment that is one contig
+        rp = synth.simulate_reads(plain, rl, 30, 78)
+        reads = np.concatenate([reads, rp], axis=0)
+        seg_off = np.concatenate([seg_off, [seg_off[-1] + rp.shape[0]]]).astype(np.uint64)
+        genomes = genomes + [plain]
+        b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+        b.build(k, genome_len_hint=L).score(8, prob)
+        contigs = b.contigs()
+        fx, shift = b.score_fixed()
+        sc = b.scores()
+        assert np.array_equal(sc["bp_score"], fx.astype(np.float64) * 2.0 ** -shift)
+        g = b.guided()
+        for s in range(n_seg + 1):
+            rs = _strs(reads[int(seg_off[s]):int(seg_off[s + 1])])
+            a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+            ofx = guided_oracle.fixed_sums(contigs[s], rs, table, 8, shift)
+            assert ofx == fx[a:e].tolist(), (k, s)                               # the steering quantity, exactly
+            want = guided_oracle.guided_paths(contigs[s], ofx, k)
+            got = [d["sequence"] for d in g[s]]
+            assert got == want, (k, s)
+            assert sum(len(x) for x in got) <= sum(len(c) for c in contigs[s]) and len(got) <= len(contigs[s])
+            o = orc.calc_breakscore(got, rs, "", 8, keys, prob, with_lev=False, with_freq=False)
+            assert [d["kmer_breaks"] for d in g[s]] == o["kmer_breaks"].tolist()
+            assert np.abs(np.array([d["bp_score"] for d in g[s]]) - o["bp_score"]).max(initial=0.0) < TOL
+        assert len(g[n_seg]) == len(contigs[n_seg])                              # nothing to chain without branching nodes... or all chained
+        b.close()
