@@ -117,6 +117,8 @@ template <class K, int TBL>
 __global__ void k_bucket_merge(const K* in_keys, const u32* in_cnt, const u64* run_off, const u32* run_len, u32 n_src, K* out_keys, u32* out_cnt,
                                const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits);
 __global__ void k_repack_reads(const u64* src, const u64* dir, u64* words_out);
+__global__ void k_piece_positions(const u64* piece_first, const u64* piece_word_off, u32 n_pieces, u64 n_reads, u32 fixed_len, u64* pos);
+__global__ void k_slice_last(const u32* a, const u64* off, u32 n, u32* out);
 
 // ---- kernels_asm.hip
 __global__ void k_chain_expand(const u64* cwords, const u64* c_off, const u64* sig_off, const u32* elem_contig, const u32* elem_skip, const u64* elem_pos,

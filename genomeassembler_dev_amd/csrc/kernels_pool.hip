@@ -169,3 +169,19 @@ __global__ void __launch_bounds__(GASM_WG) k_repack_reads(const u64* __restrict_
         words_out[woff + w] = v;
     }
 }
+
+// base position of every read of a pooled rank's own segments: read r lies in piece p = the last piece with
+// piece_first[p] <= r, at word piece_word_off[p], its (r - piece_first[p])-th read of fixed_len bases
+__global__ void __launch_bounds__(GASM_WG) k_piece_positions(const u64* __restrict__ piece_first, const u64* __restrict__ piece_word_off, u32 n_pieces,
+                                                             u64 n_reads, u32 fixed_len, u64* __restrict__ pos) {
+    for (u64 r = (u64)blockIdx.x * GASM_WG + threadIdx.x; r < n_reads; r += (u64)gridDim.x * GASM_WG) {
+        const u32 p = upper_seg<u64>(piece_first, n_pieces, r);
+        pos[r] = piece_word_off[p] * 32 + (r - piece_first[p]) * fixed_len;
+    }
+}
+
+// out[s] = a[off[s + 1] - 1] (0 for an empty slice): the totals of per-segment inclusive scans
+__global__ void __launch_bounds__(GASM_WG) k_slice_last(const u32* __restrict__ a, const u64* __restrict__ off, u32 n, u32* __restrict__ out) {
+    const u32 s = blockIdx.x * GASM_WG + threadIdx.x;
+    if (s < n) out[s] = off[s + 1] > off[s] ? a[off[s + 1] - 1] : 0u;
+}

@@ -252,12 +252,13 @@ int DevReads::simulate(gasm_ctx* ctx, const char* genomes, const u64* genome_off
             d_start.as<u32>(), d_keep.as<u32>());
     if (doff[S]) HIPCHK(hipMemcpyAsync(d_rank.p, d_keep.p, doff[S] * 4, hipMemcpyDeviceToDevice, ctx->stream));
     GLAUNCH(ctx, "k_seg_scan_incl", k_seg_scan_incl<u32>, dim3(S), dim3(1024), 0, d_rank.as<u32>(), d_doff.as<u64>());
-    // kept reads per segment = the last rank of the segment
+    // kept reads per segment = the last rank of the segment (one small kernel + one copy, not a copy per segment)
     std::vector<u32> last(S, 0);
     u32 herr = 0;
+    GCHK(d_sro.ensure((size_t)S * 4 + 8));
+    GLAUNCH(ctx, "k_slice_last", k_slice_last, dim3(ceil_div_u64(S, GASM_WG)), dim3(GASM_WG), 0, d_rank.as<u32>(), d_doff.as<u64>(), S, d_sro.as<u32>());
     HIPCHK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
-    for (u32 s = 0; s < S; ++s)
-        if (doff[s + 1] > doff[s]) HIPCHK(hipMemcpyAsync(&last[s], d_rank.as<u32>() + doff[s + 1] - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(last.data(), d_sro.p, (size_t)S * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (herr) { gasm_set_error("a genome holds a base outside upper-case ACGT"); return GASM_ERR_NON_ACGT; }
     std::vector<u64> sro((size_t)S + 1, 0);

@@ -307,14 +307,23 @@ int gasm_pool_set_reads(gasm_pool* p, const void* d_words, uint64_t n_words, uin
     for (u32 s = 0; s < S; ++s) o.h_seg_read_off[s + 1] += o.h_seg_read_off[s];
     o.n_reads = o.h_seg_read_off[S];
     o.total_bases = o.n_reads * (u64)flen;
-    std::vector<u64> pos(std::max<u64>(o.n_reads, 1));
+    // the reads' base positions, computed on the device from the piece directory (only pieces with reads are listed)
+    std::vector<u64> pfirst, pword;
     u64 r = 0;
-    for (u32 i = 0; i < n_pieces; ++i)
-        for (u64 q = 0; q < piece_reads[i]; ++q) pos[r++] = piece_word_off[i] * 32 + q * flen;
+    for (u32 i = 0; i < n_pieces; ++i) {
+        if (piece_reads[i]) { pfirst.push_back(r); pword.push_back(piece_word_off[i]); }
+        r += piece_reads[i];
+    }
     GCHK(o.d_words.ensure((n_words + 4) * 8));
     if (n_words) HIPCHK(hipMemcpyAsync(o.d_words.p, d_words, n_words * 8, hipMemcpyDeviceToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(static_cast<char*>(o.d_words.p) + n_words * 8, 0, 32, ctx->stream));
-    GCHK(up(ctx, o.d_read_off, pos.data(), pos.size() * 8));
+    GCHK(o.d_read_off.ensure(std::max<u64>(o.n_reads, 1) * 8));
+    if (o.n_reads) {
+        GCHK(up(ctx, p->d_roff, pfirst.data(), pfirst.size() * 8));
+        GCHK(up(ctx, p->d_off, pword.data(), pword.size() * 8));
+        GLAUNCH(ctx, "k_piece_positions", k_piece_positions, dim3(std::min<u32>(ceil_div_u64(o.n_reads, GASM_WG), (u32)ctx->n_cu * 8u)), dim3(GASM_WG), 0,
+                p->d_roff.as<u64>(), p->d_off.as<u64>(), (u32)pfirst.size(), o.n_reads, flen, o.d_read_off.as<u64>());
+    }
     GCHK(up(ctx, o.d_seg_read_off, o.h_seg_read_off.data(), ((size_t)S + 1) * 8));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     p->reads_set = true;
