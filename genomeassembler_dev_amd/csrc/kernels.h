@@ -53,6 +53,10 @@ __device__ __forceinline__ u32 graph_lower_bound(const GraphView& gv, u32 seg, c
     const u16* f = gv.fdir + (u64)gb * (nbin + 1) + (kfield(t, bshift) & (nbin - 1));
     u32 lo = base + f[0];
     u32 hi = base + f[1];
+    // (a directory that is not one — a bucket of a failed build attempt whose kernels were queued ahead of its report —
+    // must still end the search: bounds inside the bucket, in order)
+    if (hi > *bucket_hi) hi = *bucket_hi;
+    if (lo > hi) lo = hi;
     while (hi - lo > 4) {                          // only skewed bins are this long
         const u32 m = (lo + hi) >> 1;
         if (kless(dk[m], t)) lo = m + 1;

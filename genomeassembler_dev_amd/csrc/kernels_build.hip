@@ -638,6 +638,10 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     __syncthreads();
     phase(3);
     if (s_tmp[5] || s_tmp[4] > (u32)LIMIT) {
+        // The host repeats the build with a larger configuration — but it does not wait for this report before the graph
+        // kernels of THIS attempt run (pipeline_build_finish), so the bucket must be left empty AND searchable: an all-zero
+        // fine directory (graph_lower_bound would otherwise bisect between whatever the allocation held)
+        for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)bucket * (BINS + 1) + i] = 0;
         if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[bucket] = 0; }
         return;
     }

@@ -106,7 +106,11 @@ k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, co
         if (n_nonempty <= 1) {
             const u32 len = n_nonempty ? run_len[(u64)j * n_src + only] : 0u;
             const u64 off = n_nonempty ? run_off[(u64)j * n_src + only] : 0ull;
-            if (len > (u32)LIMIT) { if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[j] = 0; } return; }
+            if (len > (u32)LIMIT) {
+                for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)j * (BINS + 1) + i] = 0;
+                if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[j] = 0; }
+                return;
+            }
             const u64 beg = bstart[j];
             for (u32 i = threadIdx.x; i < len; i += GASM_WG) { out_keys[beg + i] = in_keys[off + i]; out_cnt[beg + i] = in_cnt[off + i]; }
             constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
@@ -142,8 +146,8 @@ k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, co
     }
     __syncthreads();
     if (s_tmp[5] || s_tmp[4] > (u32)LIMIT) {
+        for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)j * (BINS + 1) + i] = 0;      // empty and searchable
         if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[j] = 0; }
-        // (the fine directory of an overflowed bucket is never used: the caller repartitions)
         return;
     }
     const u32 d = s_tmp[4];

@@ -134,7 +134,7 @@ int gasm_pool_local_runs(gasm_pool* p, int k, int bbits, const uint32_t** run_le
 
 int gasm_pool_pack_runs(gasm_pool* p, const uint32_t* bucket_ix, uint64_t n, void* d_keys_out, void* d_counts_out) {
     POOL_GUARD_BEGIN
-    if (!p || (n && (!bucket_ix || !d_keys_out || !d_counts_out))) { gasm_set_error("gasm_pool_pack_runs: null argument"); return GASM_ERR_INVALID; }
+    if (!p || (n && !bucket_ix)) { gasm_set_error("gasm_pool_pack_runs: null argument"); return GASM_ERR_INVALID; }
     if (n == 0) return GASM_OK;
     gasm_ctx* ctx = p->ctx;
     HIPCHK(hipSetDevice(ctx->device));
@@ -145,6 +145,8 @@ int gasm_pool_pack_runs(gasm_pool* p, const uint32_t* bucket_ix, uint64_t n, voi
         off[i] = run;
         run += p->h_len[bucket_ix[i]];
     }
+    if (run == 0) return GASM_OK;                 // every listed run is empty: nothing to write (the buffers may be null)
+    if (!d_keys_out || !d_counts_out) { gasm_set_error("gasm_pool_pack_runs: null output buffer"); return GASM_ERR_INVALID; }
     GCHK(up(ctx, p->d_list, bucket_ix, n * 4));
     GCHK(up(ctx, p->d_off, off.data(), n * 8));
     const BuildState& bs = p->bs;

@@ -742,3 +742,26 @@ def test_guided_traversal_against_own_restatement(qtable):
             assert np.abs(np.array([d["bp_score"] for d in g[s]]) - o["bp_score"]).max(initial=0.0) < TOL
         assert len(g[n_seg]) == len(contigs[n_seg])                              # nothing to chain without branching nodes... or all chained
         b.close()
+
+
+@pytest.mark.timeout(180)
+def test_failed_attempt_is_safe_to_run_ahead(qtable):
+    """Found by tools/soak.py: a build whose hint is far too small overflows its buckets; the graph kernels of that attempt
+    are queued before the host reads the report, so they run on the failed attempt's leftovers — which must be empty but
+    searchable (an unwritten fine directory once sent graph_lower_bound into an endless bisection).  128-bit keys, a
+    three-letter genome, hint = L / 7; and the same with 64-bit keys."""
+    keys, prob = qtable
+    for k, rl, L, hint, alphabet in ((63, 152, 5368, 766, b"GCGA"), (27, 90, 6000, 100, b"ACGT"), (41, 120, 3000, 60, b"AACC")):
+        lut = np.frombuffer(alphabet, dtype=np.uint8)
+        parts, off, gens = [], [0], []
+        for s in range(2):
+            g = lut[np.random.default_rng(40 + s).integers(0, 4, L)]
+            r = synth.simulate_reads(g, rl, 30, 50 + s)
+            parts.append(r); off.append(off[-1] + r.shape[0]); gens.append(g)
+        reads = np.concatenate(parts, axis=0)
+        b = ga.SegmentBatch(reads.reshape(-1), np.array(off, dtype=np.uint64), fixed_len=rl)
+        for _ in range(2):
+            b.build(k, genome_len_hint=hint).score(8, prob)
+            b.ctx.sync()                                  # the queued attempt (and its successors) must come to an end
+        _check_segments_vs_oracle(b, reads, np.array(off, dtype=np.uint64), gens, range(2), k, keys, prob)
+        b.close()

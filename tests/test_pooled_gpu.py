@@ -78,3 +78,37 @@ def test_pooled_ownership_functions():
             assert cnt.min() > 0.8 * 6400 / world and cnt.max() < 1.2 * 6400 / world      # even enough to balance the merge
         o2 = pooled.segment_owner(100, world)
         assert (np.diff(o2) >= 0).all() and set(o2.tolist()) == set(range(min(world, 100)))
+
+
+def test_pooled_with_empty_ranks(qtable):
+    """more ranks than there is work: ranks whose buckets receive no record, a rank without reads, a segment without reads"""
+    keys, prob = qtable
+    k, rl = 9, 20
+    g = synth.make_segment(5, 200, planted=False)
+    r0 = synth.simulate_reads(g, rl, 6, 6)
+    reads = r0
+    seg_off = np.array([0, r0.shape[0], r0.shape[0]], dtype=np.uint64)          # second segment: no reads at all
+    single = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    single.build(k).score(8, prob)
+    want = single.contigs()
+    for world, bbits in ((4, 0), (8, 2), (3, 1)):
+        be = {}
+        for r in range(world):
+            rr, so = _shard_reads(reads, seg_off, r, world)
+            if r == world - 1:
+                rr, so = rr[:0], np.zeros(3, dtype=np.uint64)                   # a rank that holds nothing
+            be[r] = pooled.GasmBackend(rr, so, rl)
+        own = pooled.pooled_build(pooled.VirtualComm(world), be, 2, k, bbits, kmer=8, table=prob)
+        got = {}
+        for r in range(world):
+            for s, d in zip(range(*own[r]), be[r].results()):
+                got[s] = d["contigs"]
+            be[r].close()
+        # the last rank's reads were dropped, so compare with a single-GPU build of the same reduced read set
+        kept = np.concatenate([_shard_reads(reads, seg_off, r, world)[0] for r in range(world - 1)], axis=0)
+        ref = ga.SegmentBatch(kept.reshape(-1), np.array([0, kept.shape[0], kept.shape[0]], dtype=np.uint64), fixed_len=rl)
+        ref.build(k)
+        assert [got[0], got[1]] == ref.contigs(), (world, bbits)
+        ref.close()
+    assert want[1] == []
+    single.close()

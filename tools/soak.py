@@ -1,0 +1,96 @@
+"""Randomised parity soak (GPU box): random (segments, length, read length, coverage, k, hint, planted repeats, alphabet)
+batches through build + score + pooled virtual ranks + guided traversal + device scaffolds, every segment against the
+oracle.  usage: python tools/soak.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401  (its HIP runtime first: genomeassembler_dev_amd/_lib.py)
+
+import genomeassembler_dev_amd as ga  # noqa: E402
+from genomeassembler_dev_amd import pooled, qtable, synth  # noqa: E402
+from oracle import orc  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+keys, prob = qtable.keys(), qtable.load_normalised()
+t0, rounds, segs = time.time(), 0, 0
+while time.time() - t0 < budget:
+    S = int(rng.integers(1, 14))
+    L = int(rng.integers(300, 6000))
+    k = int(rng.choice([3, 5, 9, 15, 21, 27, 31, 32, 33, 45, 51, 63]))
+    rl = int(rng.integers(k, k + 120))
+    cov = float(rng.uniform(3, 40))
+    planted = bool(rng.integers(0, 2))
+    alphabet = rng.choice(["ACGT", "ACGT", "ACGT", "AC", "ACG"])
+    hint = int(rng.choice([0, L, max(1, L // 7)]))
+    genomes, parts, off = [], [], [0]
+    for s in range(S):
+        g = synth.make_segment(int(rng.integers(1 << 30)), L, planted=planted)
+        if alphabet != "ACGT":
+            lut = np.frombuffer(alphabet.encode(), dtype=np.uint8)
+            g = lut[np.frombuffer(g.tobytes(), dtype=np.uint8) % len(lut)]
+        r = synth.simulate_reads(g, rl, cov, int(rng.integers(1 << 30)))
+        genomes.append(g)
+        parts.append(r)
+        off.append(off[-1] + r.shape[0])
+    reads = np.concatenate(parts, axis=0)
+    seg_off = np.array(off, dtype=np.uint64)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    b.build(k, genome_len_hint=hint).score(8, prob)
+    contigs, sc = b.contigs(), b.scores()
+    tag = f"S={S} L={L} k={k} rl={rl} cov={cov:.1f} planted={planted} alphabet={alphabet} hint={hint}"
+    for s in range(S):
+        rs = [x.tobytes().decode() for x in reads[off[s]:off[s + 1]]]
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+        assert contigs[s] == ref["contigs"], (tag, s, "contigs")
+        dk, dm = b.distinct_kmers(s)
+        assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist(), (tag, s, "counts")
+        o = orc.calc_breakscore(contigs[s], rs, "", 8, keys, prob, with_lev=False, with_freq=False)
+        a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+        assert sc["kmer_breaks"][a:e].tolist() == o["kmer_breaks"].tolist(), (tag, s, "breaks")
+        assert np.abs(sc["bp_score"][a:e] - o["bp_score"]).max(initial=0.0) < 1e-9, (tag, s, "score")
+        segs += 1
+    # pooled virtual ranks = single GPU
+    if rounds % 3 == 0:
+        world = int(rng.integers(1, 5))
+        bbits = int(min(rng.integers(0, 6), 2 * (k - 1)))
+        be = {}
+        for r in range(world):
+            pr = [p[r::world] for p in parts]
+            o2 = np.concatenate([[0], np.cumsum([x.shape[0] for x in pr])]).astype(np.uint64)
+            be[r] = pooled.GasmBackend(np.concatenate(pr, axis=0), o2, rl)
+        try:
+            own = pooled.pooled_build(pooled.VirtualComm(world), be, S, k, bbits, kmer=8, table=prob)
+            for r in range(world):
+                a0, b0 = own[r]
+                for s, d in zip(range(a0, b0), be[r].results()):
+                    assert d["contigs"] == contigs[s], (tag, "pooled", world, s)
+                    ca, ce = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+                    assert d["kmer_breaks"].tolist() == sc["kmer_breaks"][ca:ce].tolist(), (tag, "pooled breaks", world, s)
+        except ga.GasmError as e:
+            if "GASM_ERR_CAPACITY" not in str(e):
+                raise                                      # (too few bucket bits for this input: the documented answer)
+        for r in range(world):
+            be[r].close()
+    # device scaffolds of one segment
+    if rounds % 4 == 1 and k >= 3:
+        s = int(rng.integers(0, S))
+        rs = [x.tobytes().decode() for x in reads[off[s]:off[s + 1]]]
+        if rs:
+            m = ga.get_contigs(ga.get_kmers_from_reads(rs, k), k, 7, matrix_rows=120)
+            try:
+                ref = orc.assemble_contigs(m.contigs, m.perm, k)
+            except IndexError:
+                ref = None
+            if ref is not None and len(m.contigs) <= 2048:
+                dv = ga.assemble_contigs(m, k, on_device=True)
+                assert dv.strings() == ref, (tag, "scaffolds", s)
+                dv.close()
+    b.close()
+    rounds += 1
+    print(f"[{time.time() - t0:6.1f} s] batch {rounds}: {tag} ok", flush=True)
+print(f"soak ok: {rounds} batches, {segs} segments against the oracle in {time.time() - t0:.0f} s")
