@@ -49,10 +49,11 @@ while time.time() - t0 < budget:
         assert contigs[s] == ref["contigs"], (tag, s, "contigs")
         dk, dm = b.distinct_kmers(s)
         assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist(), (tag, s, "counts")
-        o = orc.calc_breakscore(contigs[s], rs, "", 8, keys, prob, with_lev=False, with_freq=False)
-        a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
-        assert sc["kmer_breaks"][a:e].tolist() == o["kmer_breaks"].tolist(), (tag, s, "breaks")
-        assert np.abs(sc["bp_score"][a:e] - o["bp_score"]).max(initial=0.0) < 1e-9, (tag, s, "score")
+        if len(contigs[s]) * len(rs) <= 1_500_000:          # (the oracle's scorer is contigs x reads x find)
+            o = orc.calc_breakscore(contigs[s], rs, "", 8, keys, prob, with_lev=False, with_freq=False)
+            a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+            assert sc["kmer_breaks"][a:e].tolist() == o["kmer_breaks"].tolist(), (tag, s, "breaks")
+            assert np.abs(sc["bp_score"][a:e] - o["bp_score"]).max(initial=0.0) < 1e-9, (tag, s, "score")
         segs += 1
     # pooled virtual ranks = single GPU
     if rounds % 3 == 0:
@@ -90,7 +91,56 @@ while time.time() - t0 < budget:
                 dv = ga.assemble_contigs(m, k, on_device=True)
                 assert dv.strings() == ref, (tag, "scaffolds", s)
                 dv.close()
+    # guided traversal against its CPU restatement (small cases: the restatement is Python)
+    if rounds % 5 == 2 and reads.shape[0] * sum(len(c) for cs in contigs for c in cs) < 4e7 and rl >= k:
+        from oracle import guided_oracle
+        table = dict(zip(keys, prob.tolist()))
+        fx, shift = b.score_fixed()
+        gd = b.guided()
+        for s in range(S):
+            rs = [x.tobytes().decode() for x in reads[off[s]:off[s + 1]]]
+            a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+            ofx = guided_oracle.fixed_sums(contigs[s], rs, table, 8, shift)
+            assert ofx == fx[a:e].tolist(), (tag, "guided sums", s)
+            assert [d["sequence"] for d in gd[s]] == guided_oracle.guided_paths(contigs[s], ofx, k), (tag, "guided", s)
     b.close()
+    # ragged reads (some shorter than k, some empty) through the general scorer; calc_breakscore with KS on random paths
+    if rounds % 5 == 3:
+        gs = genomes[0].tobytes().decode()
+        rr = [gs[a:a + int(rng.integers(0, 3 * k + 10))] for a in rng.integers(0, max(1, L - 1), 400)]
+        bb = ga.SegmentBatch.from_strings([rr, rr[:37]])
+        bb.build(k).score(8, prob)
+        cs2, sc2 = bb.contigs(), bb.scores()
+        for s, rs in enumerate([rr, rr[:37]]):
+            ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+            assert cs2[s] == ref["contigs"], (tag, "ragged contigs", s)
+            o = orc.calc_breakscore(cs2[s], rs, "", 8, keys, prob, with_lev=False, with_freq=False)
+            a, e = int(sc2["seg_contig_off"][s]), int(sc2["seg_contig_off"][s + 1])
+            assert sc2["kmer_breaks"][a:e].tolist() == o["kmer_breaks"].tolist(), (tag, "ragged breaks", s)
+            assert np.abs(sc2["bp_score"][a:e] - o["bp_score"]).max(initial=0.0) < 1e-9
+        bb.close()
+        # (reads of >= 4 bases and paths of >= 8: no break window is cut short by the end of a path — there the reference
+        # inserts keys into its table and its path_freq is no longer the vector the KS statistic is defined on)
+        paths = [p for p in (gs[a:a + int(rng.integers(8, 400))] for a in rng.integers(0, max(1, L - 1), 40)) if len(p) >= 8] + [gs]
+        rr = [r for r in rr if len(r) >= 4]
+        m = ga.calc_breakscore(paths, rr, gs, 8, keys, prob, with_lev=True, with_freq=True, with_ks=True)
+        o = orc.calc_breakscore(paths, rr, gs, 8, keys, prob, with_lev=True, with_freq=True)
+        assert m["kmer_breaks"].tolist() == o["kmer_breaks"].tolist() and m["lev_dist_vs_true"].tolist() == o["lev_dist_vs_true"].tolist(), (tag, "api")
+        y = orc.kmer_from_seq(gs, 8, keys, prob)
+        for i in range(len(paths)):
+            r = orc.ks_statistic(o["path_freq"][i], y)
+            assert (np.isnan(r) and np.isnan(m["stat_test_KS"][i])) or abs(m["stat_test_KS"][i] - r) < 1e-9, (tag, "ks", i)
+    # simulated reads against the oracle's sampler
+    if rounds % 5 == 4 and alphabet == "ACGT":
+        gl = [g.tobytes().decode() for g in genomes[:3]]
+        sd = int(rng.integers(1 << 40))
+        wt = prob if rng.integers(0, 2) else None
+        sb = ga.SegmentBatch.simulate(gl, rl, cov, sd, kmer=8, table=wt)
+        so, st = sb.read_starts()
+        for s, g in enumerate(gl):
+            ref = orc.simulate_starts(g, s, rl, cov, sd, 8, keys if wt is not None else None, wt)
+            assert st[int(so[s]):int(so[s + 1])].tolist() == ref.tolist(), (tag, "sim", s)
+        sb.close()
     rounds += 1
     print(f"[{time.time() - t0:6.1f} s] batch {rounds}: {tag} ok", flush=True)
 print(f"soak ok: {rounds} batches, {segs} segments against the oracle in {time.time() - t0:.0f} s")
