@@ -433,7 +433,8 @@ template __global__ void k_bucket_scatter<K128>(ReadSet, const uint4*, int, int,
 // into its bin's range, bins of more than one key are finished by a per-bin insertion sort; if any bin is long (skewed
 // keys) the workgroup falls back to a bitonic sort.  The bin offsets are kept as the fine directory of the graph
 // kernels.  A bucket with more than 11/16*TBL distinct keys raises *overflow (the host re-partitions).
-// launch bounds: 2048 slots of 64-bit keys fit five workgroups per CU in LDS (<= 96 registers), the other variants three.
+// launch bounds: 2048 slots of 64-bit keys fit five workgroups per CU in LDS (<= 96 registers), of 128-bit keys three,
+// 4096 slots two.
 // ================================================================================================================
 #define GASM_SLOT_LOCKED 0xFFFFFFFFu
 
@@ -491,7 +492,7 @@ __device__ __forceinline__ bool dedup_step(K128* t_key, u32* t_cnt, u32* n_disti
 }
 
 template <class K, int TBL>
-__global__ void __launch_bounds__(GASM_WG, (TBL == 2048 && sizeof(K) == 8) ? 5 : 3)
+__global__ void __launch_bounds__(GASM_WG, TBL == 4096 ? 2 : sizeof(K) == 8 ? 5 : 3)
 k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
                u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg, unsigned long long* __restrict__ stamps) {
     constexpr int LIMIT = TBL / 16 * 11;
