@@ -84,7 +84,7 @@ __device__ __forceinline__ bool merge_step(K128* t_key, u32* t_cnt, u32* n_disti
 // bstart[j+1] - bstart[j] >= min(sum of the lengths, table limit)), its length in bucket_d[j], the fine directory of
 // bucket j.  *overflow is raised when the union does not fit the table (the partition needs more bucket bits).
 template <class K, int TBL>
-__global__ void __launch_bounds__(GASM_WG, 3)
+__global__ void __launch_bounds__(GASM_WG, TBL == 4096 ? 2 : 3)      // (LDS: 56 KB / 44 KB per workgroup)
 k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, const u64* __restrict__ run_off, const u32* __restrict__ run_len,
                u32 n_src, K* __restrict__ out_keys, u32* __restrict__ out_cnt, const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
                u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits) {

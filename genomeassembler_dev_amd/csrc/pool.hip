@@ -113,11 +113,8 @@ int gasm_pool_local_runs(gasm_pool* p, int k, int bbits, const uint32_t** run_le
         *run_len = p->h_len.data();
         return GASM_OK;
     }
-    u64 maxNs = 0;
-    for (u64 v : bs.h_seg_nk) maxNs = std::max(maxNs, v);
-    (void)maxNs;
     bs.small_tbl = true;        // the caller chose bbits for buckets of <= ~900 distinct k-mers; a bucket that does not fit retries below
-    for (int attempt = 0;; ++attempt) {
+    for (;;) {
         distinct_caps(bs, S);
         GCHK(launch_distinct(ctx, p->rd, bs));
         const int ov = read_lens(p, p->n_runs);
