@@ -142,6 +142,7 @@ def main():
         return be, step, stats, n_km, int(off[-1])
 
     dominant = ("k_bucket_scatter", "k_bucket_dedup")
+    profiled = dominant + ("k_score_reads_graph",)
     reads = seg_off = batch = None
     if args.mode == "segments":
         # rank r owns the contiguous block of global segments parallel.shard_bounds(nseg * world, world)[r]
@@ -153,12 +154,17 @@ def main():
         def step():
             batch.build(k, genome_len_hint=L)
             batch.score(8, table)
-        dt, prof = timed(step, args.steps, args.warmup, profile=dominant)
+        dt, prof = timed(step, args.steps, args.warmup, profile=profiled)
         seg, keys, mult, _w = batch.distinct()
         n_distinct = int(seg[-1])
+        sc_all = batch.scores()
+        # SURVEY §8(d) bytes of the scoring: packed reads + packed paths + 16 B per hit + 32 B of results per path
+        score_bytes = (n_reads * rl / 4.0 + float(np.sum(sc_all["sequence_len"])) / 4.0 + 16.0 * float(np.sum(sc_all["kmer_breaks"]))
+                       + 32.0 * len(sc_all["kmer_breaks"]))
     else:
         be, step, pstats, n_kmers, n_reads = pooled_setup()
-        dt, prof = timed(step, args.steps, args.warmup, profile=dominant)
+        dt, prof = timed(step, args.steps, args.warmup, profile=profiled)
+        score_bytes = None
         res = be.results(with_scores=False)
         n_distinct = sum(len(d["counts"]) for d in res)
 
@@ -182,6 +188,18 @@ def main():
                     "other": {n: {"avg_launch_ms": round(prof[n][0] / prof[n][1], 4),
                                   "achieved_GBs": round(alg_bytes[n] / (prof[n][0] / prof[n][1] / 1e3) / 1e9, 1)}
                               for n in dominant if n != dom and n in prof and prof[n][1]}}
+
+    if roofline and score_bytes and prof.get("k_score_reads_graph", (0.0, 0))[1]:
+        # (low by construction: the scorer's work is index look-ups and compares, not bytes — see the compares/s figure)
+        sms = prof["k_score_reads_graph"][0] / prof["k_score_reads_graph"][1]
+        roofline["other"]["k_score_reads_graph"] = {"avg_launch_ms": round(sms, 4), "algorithmic_bytes_per_launch": int(score_bytes),
+                                                    "achieved_GBs": round(score_bytes / (sms / 1e3) / 1e9, 1)}
+    # the whole step against the same peak: SURVEY §8(d)'s per-unit bytes of every stage (k-mer pass: packed bases in, key
+    # out, key in again = 2W + 0.25*rl/(rl-k+1) per k-mer; graph + contigs + scoring: 33 B per distinct k-mer; L bases per segment)
+    if roofline and args.mode == "segments":
+        step_bytes = n_kmers * (2 * key_bytes + 0.25 * rl / (rl - k + 1)) + n_distinct * 33.0 + float(nseg) * L    # this rank's
+        step_gbs = step_bytes / (dt / args.steps) / 1e9
+        roofline["step"] = {"algorithmic_bytes": int(step_bytes), "achieved": round(step_gbs, 1), "frac": round(step_gbs / HBM_PEAK_GBS, 4)}
 
     # HBM traffic of the dominant kernel from the committed PMC passes of this workload (rocprofv3 --pmc FETCH_SIZE and
     # --pmc WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950).  The file
