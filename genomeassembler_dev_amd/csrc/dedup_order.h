@@ -7,8 +7,10 @@
 // The d distinct keys of the LDS table end up sorted in t_key[0, d) with their counts in t_cnt[0, d), and the fine
 // directory of the bucket is written.  Counting sort on the key bits below the bucket prefix (TBL/4 bins; close to
 // uniform there) + per-bin insertion sort; if any bin is long (skewed keys) a bitonic sort.  s_start must be zero on
-// entry, s_tmp[6] (longest bin) too; every thread of the workgroup calls it (it contains barriers).
-template <class K, int TBL>
+// entry (unless BINS_IN_TABLE), s_tmp[6] (longest bin) too; every thread of the workgroup calls it (it contains barriers).
+// BINS_IN_TABLE: s_start / s_cur point into the table itself, behind the LIMIT entries the sorted result can have (the
+// caller's LDS is then the table alone — one more workgroup per CU); they are zeroed here, once every slot is in registers.
+template <class K, int TBL, bool BINS_IN_TABLE = false>
 __device__ __forceinline__ void dedup_order(K* t_key, u32* t_cnt, u32* s_start, u32* s_cur, u32* s_tmp, u16* __restrict__ fdir,
                                             u32 bucket, int low_bits, u32 d) {
     constexpr int BINS = TBL / 4;
@@ -24,8 +26,16 @@ __device__ __forceinline__ void dedup_order(K* t_key, u32* t_cnt, u32* s_start, 
         rk[q] = t_key[q * GASM_WG + threadIdx.x];
         rc[q] = t_cnt[q * GASM_WG + threadIdx.x];
         if (WIDE && rc[q] == 0) rk[q] = key_empty<K>();      // 128-bit tables mark free slots by the count
-        if (!kis_empty(rk[q])) atomicAdd(&s_start[kfield(rk[q], bshift) & (BINS - 1)], 1u);
     }
+    if constexpr (BINS_IN_TABLE) {
+        __syncthreads();   // the table is in registers: its tail may become the bins
+        for (u32 i = threadIdx.x; i < (u32)BINS; i += GASM_WG) s_start[i] = 0;
+        if (threadIdx.x == 0) s_tmp[6] = 0;      // (s_tmp may live in the table too)
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < SL; ++q)
+        if (!kis_empty(rk[q])) atomicAdd(&s_start[kfield(rk[q], bshift) & (BINS - 1)], 1u);
     __syncthreads();   // all table reads and all bin counts are done
     {
         constexpr int PER = BINS / GASM_WG;   // 4 or 2

@@ -433,8 +433,11 @@ template __global__ void k_bucket_scatter<K128>(ReadSet, const uint4*, int, int,
 // into its bin's range, bins of more than one key are finished by a per-bin insertion sort; if any bin is long (skewed
 // keys) the workgroup falls back to a bitonic sort.  The bin offsets are kept as the fine directory of the graph
 // kernels.  A bucket with more than 11/16*TBL distinct keys raises *overflow (the host re-partitions).
-// launch bounds: 2048 slots of 64-bit keys fit five workgroups per CU in LDS (<= 96 registers), of 128-bit keys three,
-// 4096 slots two.
+// LDS and launch bounds: the workgroup's LDS is the table and nothing else (the ordering phase's bins live in the table's
+// tail, and with 128-bit keys the workgroup's counters live in the table's last set), so 2048 slots of 128-bit keys are
+// exactly a quarter of the CU's 160 KB: four workgroups per CU instead of three took the kernel from 2.46 to 2.04 ms on
+// cfg4 — it lives on LDS round trips in flight, i.e. on waves.  64-bit keys: 24 KB, six workgroups would fit, but 80
+// registers per lane spill in the streaming loop (0.61 ms against 0.45): five.  4096 slots: three.
 // ================================================================================================================
 #define GASM_SLOT_LOCKED 0xFFFFFFFFu
 
@@ -487,12 +490,12 @@ __device__ __forceinline__ bool dedup_step(K128* t_key, u32* t_cnt, u32* n_disti
         const u64x2 kq = lds_load128(&t_key[2 * set + q]);
         if (kq.x == key.hi && kq.y == key.lo) { atomicAdd(&t_cnt[2 * set + q], 1u); return true; }
     }
-    set = (set + 1) & (NSETS - 1);
+    set = set + 1 >= NSETS - 1 ? 0u : set + 1;                // (the last set is not part of the table: k_bucket_dedup's counters)
     return false;
 }
 
 template <class K, int TBL>
-__global__ void __launch_bounds__(GASM_WG, TBL == 4096 ? 2 : sizeof(K) == 8 ? 5 : 3)
+__global__ void __launch_bounds__(GASM_WG, TBL == 4096 ? 3 : sizeof(K) == 8 ? 5 : 4)
 k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
                u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg, unsigned long long* __restrict__ stamps) {
     constexpr int LIMIT = TBL / 16 * 11;
@@ -504,9 +507,26 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     static_assert(TBL == 4096 || TBL == 2048, "table size");
     __shared__ __align__(32) K t_key[TBL];
     __shared__ __align__(16) u32 t_cnt[TBL];
-    __shared__ u32 s_start[BINS];
-    __shared__ u32 s_cur[BINS];
-    __shared__ u32 s_tmp[8];
+    // 64-bit keys: eight words beside the table.  128-bit keys: the table alone is 40 KB, a quarter of the CU's LDS, and four
+    // workgroups fit only if not a word is added — its last set is kept out of the hashing, the two count words of that set
+    // hold [4] and [5] while the bucket streams in, and the ordering phase (which needs eight words) uses the set's key slots
+    u32 *s_tmp, *w_distinct, *w_overflow;                  // [4] distinct keys so far, [5] the table cannot take the bucket
+    if constexpr (WIDE) {
+        s_tmp = reinterpret_cast<u32*>(&t_key[TBL - 2]);
+        w_distinct = &t_cnt[TBL - 2];
+        w_overflow = &t_cnt[TBL - 1];
+    } else {
+        __shared__ u32 s_tmp_narrow[8];
+        s_tmp = s_tmp_narrow;
+        w_distinct = &s_tmp_narrow[4];
+        w_overflow = &s_tmp_narrow[5];
+    }
+    // the bins of the ordering phase live in the table's tail, behind the LIMIT entries a sorted bucket can have (dedup_order):
+    // the workgroup's LDS is the table (+ 32 bytes for 64-bit keys) — 24 / 40 / 48 KB: four workgroups per CU with 128-bit
+    // keys, three with 4096 slots; with 64-bit keys and 2048 slots registers, not LDS, keep it at five
+    static_assert((TBL - LIMIT) * sizeof(K) >= 2 * BINS * sizeof(u32), "the bins must fit behind the sorted entries");
+    u32* const s_start = reinterpret_cast<u32*>(t_key + LIMIT);
+    u32* const s_cur = s_start + BINS;
     // diagnostic only (stamps == nullptr in production): per-phase wave-0 tick totals, summed over workgroups
     unsigned long long tph = stamps ? wall_clock64() : 0ull;
     auto phase = [&](int i) {
@@ -517,8 +537,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     const u64 n = end - beg;
     const u32 warm = (u32)(dbg >> 2) & 3u;        // iterations taken key by key (64-bit keys)
     for (u32 i = threadIdx.x; i < TBL; i += GASM_WG) { t_key[i] = key_empty<K>(); t_cnt[i] = 0; }
-    for (u32 i = threadIdx.x; i < BINS; i += GASM_WG) s_start[i] = 0;
-    if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }  // [4] distinct so far, [5] overflow, [6] longest bin
+    if (!WIDE && threadIdx.x == 0) { *w_distinct = 0; *w_overflow = 0; s_tmp[6] = 0; }   // ([6] longest bin: dedup_order zeroes it when the bins live in the table)
     __syncthreads();
     phase(0);
     // stream: four 16-byte loads per thread in flight (the loop is latency-bound otherwise), each fully coalesced across
@@ -545,8 +564,8 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
             for (int q = 0; q < 4; ++q) { kx[2 * q] = (u64)v[q].x | ((u64)v[q].y << 32); kx[2 * q + 1] = (u64)v[q].z | ((u64)v[q].w << 32); }
         }
         if (c + 4 * GASM_WG < nch) fetch(c + 4 * GASM_WG);
-        if ((dbg & 3) == 1) { u64 x = 0; for (int q = 0; q < KPL; ++q) x ^= khash(kx[q]); if (x == 0x1234567) s_tmp[6] = 1; continue; }
-        if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { s_tmp[5] = 1; break; }
+        if ((dbg & 3) == 1) { u64 x = 0; for (int q = 0; q < KPL; ++q) x ^= khash(kx[q]); if (x == 0x1234567) *w_overflow = 1; continue; }
+        if (__hip_atomic_load(w_distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { *w_overflow = 1; break; }
         if constexpr (!WIDE) {
             // While the table fills (the first `warm` iterations: 2048 keys each, ~600 distinct per bucket) nearly every
             // key misses its home set, and the batched form below would send all eight keys of every lane through the slow
@@ -559,8 +578,8 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
                     if (kis_filler(key)) continue;
                     u32 st = khash(key) >> (32 - LOG_SETS);
                     bool ok = false;
-                    for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
-                    if (!ok) s_tmp[5] = 1;
+                    for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, w_distinct, key, st);
+                    if (!ok) *w_overflow = 1;
                 }
                 continue;
             }
@@ -595,8 +614,8 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
                 for (u32 e = 1; e < 8; ++e) if (e == q) key = kx[e];
                 u32 st = khash(key) >> (32 - LOG_SETS);
                 bool ok = false;
-                for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
-                if (!ok) s_tmp[5] = 1;
+                for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, w_distinct, key, st);
+                if (!ok) *w_overflow = 1;
             }
         } else {
             // 128-bit keys: the four home sets' count words and both slots are read together; the misses are worked off
@@ -606,7 +625,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
             u64x2 k0[4], k1[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                set[q] = khash(kx[q]) >> (32 - LOG_SETS);
+                set[q] = min(khash(kx[q]) >> (32 - LOG_SETS), NSETS - 2);      // (the last set holds the workgroup's counters)
                 __asm__ volatile("" ::: "memory");
                 cn[q] = *reinterpret_cast<const uint2*>(&t_cnt[2 * set[q]]);
                 k0[q] = lds_load128(&t_key[2 * set[q]]);
@@ -628,17 +647,17 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
                 K128 key = kx[0];
 #pragma unroll
                 for (u32 e = 1; e < 4; ++e) if (e == q) key = kx[e];
-                u32 st = khash(key) >> (32 - LOG_SETS);
+                u32 st = min(khash(key) >> (32 - LOG_SETS), NSETS - 2);
                 bool ok = false;
-                for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
-                if (!ok) s_tmp[5] = 1;
+                for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, w_distinct, key, st);
+                if (!ok) *w_overflow = 1;
             }
         }
     }
     phase(2);
     __syncthreads();
     phase(3);
-    if (s_tmp[5] || s_tmp[4] > (u32)LIMIT) {
+    if (*w_overflow || *w_distinct > (u32)LIMIT) {
         // The host repeats the build with a larger configuration — but it does not wait for this report before the graph
         // kernels of THIS attempt run (pipeline_build_finish), so the bucket must be left empty AND searchable: an all-zero
         // fine directory (graph_lower_bound would otherwise bisect between whatever the allocation held)
@@ -646,9 +665,9 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
         if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[bucket] = 0; }
         return;
     }
-    const u32 d = s_tmp[4];
+    const u32 d = *w_distinct;
     if ((dbg & 3) == 1 || (dbg & 3) == 2) { if (threadIdx.x == 0) bucket_d[bucket] = d; return; }
-    dedup_order<K, TBL>(t_key, t_cnt, s_start, s_cur, s_tmp, fdir, bucket, low_bits, d);
+    dedup_order<K, TBL, true>(t_key, t_cnt, s_start, s_cur, s_tmp, fdir, bucket, low_bits, d);
     phase(4);
     for (u32 i = threadIdx.x; i < d; i += GASM_WG) { keys[beg + i] = t_key[i]; mult[beg + i] = t_cnt[i]; }
     if (threadIdx.x == 0) bucket_d[bucket] = d;
