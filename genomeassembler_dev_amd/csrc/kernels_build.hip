@@ -494,8 +494,21 @@ __device__ __forceinline__ bool dedup_step(K128* t_key, u32* t_cnt, u32* n_disti
     return false;
 }
 
+// 16-byte loads per thread and iteration of the streaming loop (= keys handled together: 2 or 1 per load) and workgroups
+// per CU, measured on MI355X: 64-bit keys 3 loads 0.463 ms (4: 0.475, 2: 0.489; five or six workgroups per CU: the same),
+// 128-bit keys (cfg4) 6 loads 1.94 ms (5: 2.01, 4: 2.04, 3: 2.26) — the wide table costs three LDS reads per key, and more
+// keys per wave in flight is what hides them.
+#ifndef GASM_DEDUP_NLD
+#define GASM_DEDUP_NLD 3
+#endif
+#ifndef GASM_DEDUP_NLDW
+#define GASM_DEDUP_NLDW 6
+#endif
+#ifndef GASM_DEDUP_WGS
+#define GASM_DEDUP_WGS 6
+#endif
 template <class K, int TBL>
-__global__ void __launch_bounds__(GASM_WG, TBL == 4096 ? 3 : sizeof(K) == 8 ? 5 : 4)
+__global__ void __launch_bounds__(GASM_WG, TBL == 4096 ? 3 : sizeof(K) == 8 ? GASM_DEDUP_WGS : 4)
 k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
                u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg, unsigned long long* __restrict__ stamps) {
     constexpr int LIMIT = TBL / 16 * 11;
@@ -540,30 +553,31 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     if (!WIDE && threadIdx.x == 0) { *w_distinct = 0; *w_overflow = 0; s_tmp[6] = 0; }   // ([6] longest bin: dedup_order zeroes it when the bins live in the table)
     __syncthreads();
     phase(0);
-    // stream: four 16-byte loads per thread in flight (the loop is latency-bound otherwise), each fully coalesced across
+    // stream: NLD 16-byte loads per thread in flight (the loop is latency-bound otherwise), each fully coalesced across
     // the wave.  Bucket ranges start and end on 128-byte lines (filler keys = EMPTY are skipped).
-    constexpr int KPL = 64 / sizeof(K);          // keys per thread and iteration: 8 or 4
+    constexpr int NLD = WIDE ? GASM_DEDUP_NLDW : TBL == 2048 ? GASM_DEDUP_NLD : 4;   // 16-byte loads per thread and iteration
+    constexpr int KPL = NLD * 16 / sizeof(K);    // keys per thread and iteration
     const u64 nch = n * sizeof(K) / 16;          // 16-byte chunks in the bucket
     const uint4* src = reinterpret_cast<const uint4*>(keys + beg);
     // the loads of the next iteration are issued before this iteration's keys go into the table, so the table work
     // (LDS latency) and the HBM latency overlap inside every wave
-    uint4 v[4];
+    uint4 v[NLD];
     auto fetch = [&](u64 c) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = c + (u64)q * GASM_WG < nch ? src[c + (u64)q * GASM_WG] : make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int q = 0; q < NLD; ++q) v[q] = c + (u64)q * GASM_WG < nch ? src[c + (u64)q * GASM_WG] : make_uint4(~0u, ~0u, ~0u, ~0u);
     };
     if (threadIdx.x < nch) fetch(threadIdx.x);
-    for (u64 c = threadIdx.x; c < nch; c += 4 * GASM_WG) {
-        if (c == (u64)threadIdx.x + 4 * GASM_WG) phase(1);   // first iteration (table fill) done
+    for (u64 c = threadIdx.x; c < nch; c += NLD * GASM_WG) {
+        if (c == (u64)threadIdx.x + NLD * GASM_WG) phase(1);   // first iteration (table fill) done
         K kx[KPL];
         if constexpr (WIDE) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { kx[q].hi = (u64)v[q].x | ((u64)v[q].y << 32); kx[q].lo = (u64)v[q].z | ((u64)v[q].w << 32); }
+            for (int q = 0; q < NLD; ++q) { kx[q].hi = (u64)v[q].x | ((u64)v[q].y << 32); kx[q].lo = (u64)v[q].z | ((u64)v[q].w << 32); }
         } else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { kx[2 * q] = (u64)v[q].x | ((u64)v[q].y << 32); kx[2 * q + 1] = (u64)v[q].z | ((u64)v[q].w << 32); }
+            for (int q = 0; q < NLD; ++q) { kx[2 * q] = (u64)v[q].x | ((u64)v[q].y << 32); kx[2 * q + 1] = (u64)v[q].z | ((u64)v[q].w << 32); }
         }
-        if (c + 4 * GASM_WG < nch) fetch(c + 4 * GASM_WG);
+        if (c + NLD * GASM_WG < nch) fetch(c + NLD * GASM_WG);
         if ((dbg & 3) == 1) { u64 x = 0; for (int q = 0; q < KPL; ++q) x ^= khash(kx[q]); if (x == 0x1234567) *w_overflow = 1; continue; }
         if (__hip_atomic_load(w_distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { *w_overflow = 1; break; }
         if constexpr (!WIDE) {
@@ -571,9 +585,9 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
             // key misses its home set, and the batched form below would send all eight keys of every lane through the slow
             // loop — 17 of a workgroup's 95 us (GASM_DBG_STAMPS).  There the keys are taken one after the other instead:
             // a key inserted by any lane at step q is a plain hit for everybody from step q + 1 on.
-            if (c < (u64)warm * 4 * GASM_WG) {
+            if (c < (u64)warm * NLD * GASM_WG) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < KPL; ++q) {
                     const u64 key = kx[q];
                     if (kis_filler(key)) continue;
                     u32 st = khash(key) >> (32 - LOG_SETS);
@@ -590,15 +604,15 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
             // are worked off afterwards in one loop in which every lane takes its own next missed key.
             u32 missed = 0;
             {
-                u32 set[8];
-                u64x2 c[8];
+                u32 set[KPL];
+                u64x2 c[KPL];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < KPL; ++q) {
                     set[q] = khash(kx[q]) >> (32 - LOG_SETS);
                     c[q] = lds_load128(&t_key[2 * set[q]]);
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < KPL; ++q) {
                     const u64 key = kx[q];
                     if (kis_filler(key)) continue;            // (before the slot test: the all-ones filler equals a free slot)
                     const int slot = c[q].x == key ? 0 : c[q].y == key ? 1 : -1;
@@ -611,7 +625,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
                 missed &= missed - 1;
                 u64 key = kx[0];
 #pragma unroll
-                for (u32 e = 1; e < 8; ++e) if (e == q) key = kx[e];
+                for (u32 e = 1; e < (u32)KPL; ++e) if (e == q) key = kx[e];
                 u32 st = khash(key) >> (32 - LOG_SETS);
                 bool ok = false;
                 for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, w_distinct, key, st);
@@ -620,11 +634,11 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
         } else {
             // 128-bit keys: the four home sets' count words and both slots are read together; the misses are worked off
             // afterwards, every lane on its own next missed key (as above)
-            u32 set[4];
-            uint2 cn[4];
-            u64x2 k0[4], k1[4];
+            u32 set[KPL];
+            uint2 cn[KPL];
+            u64x2 k0[KPL], k1[KPL];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < KPL; ++q) {
                 set[q] = min(khash(kx[q]) >> (32 - LOG_SETS), NSETS - 2);      // (the last set holds the workgroup's counters)
                 __asm__ volatile("" ::: "memory");
                 cn[q] = *reinterpret_cast<const uint2*>(&t_cnt[2 * set[q]]);
@@ -633,7 +647,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
             }
             u32 missed = 0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < KPL; ++q) {
                 const K128 key = kx[q];
                 if (kis_filler(key)) continue;
                 const bool r0 = cn[q].x != 0 && cn[q].x != GASM_SLOT_LOCKED, r1 = cn[q].y != 0 && cn[q].y != GASM_SLOT_LOCKED;
@@ -646,7 +660,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
                 missed &= missed - 1;
                 K128 key = kx[0];
 #pragma unroll
-                for (u32 e = 1; e < 4; ++e) if (e == q) key = kx[e];
+                for (u32 e = 1; e < (u32)KPL; ++e) if (e == q) key = kx[e];
                 u32 st = min(khash(key) >> (32 - LOG_SETS), NSETS - 2);
                 bool ok = false;
                 for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, w_distinct, key, st);
