@@ -10,9 +10,11 @@
 // entry (unless BINS_IN_TABLE), s_tmp[6] (longest bin) too; every thread of the workgroup calls it (it contains barriers).
 // BINS_IN_TABLE: s_start / s_cur point into the table itself, behind the LIMIT entries the sorted result can have (the
 // caller's LDS is then the table alone — one more workgroup per CU); they are zeroed here, once every slot is in registers.
-template <class K, int TBL, bool BINS_IN_TABLE = false>
+// RANGED (k_bucket_dedup_multi: the table holds one key sub-range of the bucket): only the bins [bin_lo, bin_hi) of the
+// fine directory are written, offset by fdir_base (the distinct keys of the sub-ranges before), and not its last entry.
+template <class K, int TBL, bool BINS_IN_TABLE = false, bool RANGED = false>
 __device__ __forceinline__ void dedup_order(K* t_key, u32* t_cnt, u32* s_start, u32* s_cur, u32* s_tmp, u16* __restrict__ fdir,
-                                            u32 bucket, int low_bits, u32 d) {
+                                            u32 bucket, int low_bits, u32 d, u32 fdir_base = 0, u32 bin_lo = 0, u32 bin_hi = TBL / 4) {
     constexpr int BINS = TBL / 4;
     constexpr int SL = TBL / GASM_WG;
     constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
@@ -48,10 +50,12 @@ __device__ __forceinline__ void dedup_order(K* t_key, u32* t_cnt, u32* s_start, 
         for (int q = 0; q < PER; ++q) {
             s_start[threadIdx.x * PER + q] = ex;
             s_cur[threadIdx.x * PER + q] = ex;
-            fdir[(u64)bucket * (BINS + 1) + threadIdx.x * PER + q] = (u16)ex;   // fine directory for the graph kernels
+            const u32 bin = threadIdx.x * PER + q;
+            if (!RANGED || (bin >= bin_lo && bin < bin_hi))
+                fdir[(u64)bucket * (BINS + 1) + bin] = (u16)(fdir_base + ex);   // fine directory for the graph kernels
             ex += c[q];
         }
-        if (threadIdx.x == GASM_WG - 1) fdir[(u64)bucket * (BINS + 1) + BINS] = (u16)ex;
+        if (!RANGED && threadIdx.x == GASM_WG - 1) fdir[(u64)bucket * (BINS + 1) + BINS] = (u16)ex;
         if (mx > 1) atomicMax(&s_tmp[6], mx);
     }
     __syncthreads();

@@ -95,6 +95,9 @@ __global__ void k_bucket_scatter(ReadSet rs, const uint4* tinfo, int k, int bbit
 template <class K, int TBL>
 __global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits, int dbg,
                                unsigned long long* stamps);
+#define GASM_BUCKET_MAX 65535   // distinct keys of one bucket (16-bit fine directory)
+template <class K>
+__global__ void k_bucket_dedup_multi(const K* keys, K* keys_out, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits);
 template <class K>
 __global__ void k_bucket_gather(const K* keys, const u32* mult, const u64* bstart, const u32* dstart, K* dk_key, u32* dk_cnt, u32* claim, u8* eflag);
 template <class K> __global__ void k_edge_target(GraphView gv, u32 n_segments, u32 chunks, u32* tgt, u32* claim);

@@ -692,6 +692,80 @@ template __global__ void k_bucket_dedup<u64, 4096>(u64*, u32*, const u64*, u32*,
 template __global__ void k_bucket_dedup<u64, 2048>(u64*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
 template __global__ void k_bucket_dedup<K128, 2048>(K128*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
 
+// ================================================================================================================
+// De-duplication of buckets that no table can hold (the last rung of pipeline_build_finish's ladder: ten bucket bits and
+// still more than LIMIT distinct keys with one prefix — skewed base composition, e.g. two-letter sequences).  Buckets are
+// key ranges, so a bucket splits into 2^r ordered sub-ranges by the r bits below its prefix: the workgroup makes 2^r
+// passes over the bucket, each pass puts the keys of one sub-range through the table, orders them and appends them to the
+// output — which is therefore sorted as a whole.  r grows until every sub-range fits.  The passes re-read the bucket, so
+// the output goes to a second array (keys_out, same layout), and the fine directory is written range by range.
+// 4096-slot tables for both key widths; a bucket may hold up to GASM_BUCKET_MAX distinct keys (16-bit directory).
+// Speed is not the point here.
+// ================================================================================================================
+template <class K>
+__global__ void __launch_bounds__(GASM_WG) k_bucket_dedup_multi(const K* __restrict__ keys, K* __restrict__ keys_out, u32* __restrict__ mult,
+                                                                const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
+                                                                u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits) {
+    constexpr int TBL = 4096, LIMIT = TBL / 16 * 11, BINS = TBL / 4, LOG_SETS = 11, LOG_BINS = 10;
+    constexpr u32 NSETS = 1u << LOG_SETS;
+    __shared__ __align__(32) K t_key[TBL];
+    __shared__ __align__(16) u32 t_cnt[TBL];
+    __shared__ u32 s_start[BINS];
+    __shared__ u32 s_cur[BINS];
+    __shared__ u32 s_tmp[8];
+    const u32 bucket = blockIdx.x;
+    const u64 beg = bstart[bucket], n = bstart[bucket + 1] - beg;
+    const int bin_bits = low_bits < LOG_BINS ? low_bits : LOG_BINS;      // the bits of a key that select its bin (dedup_order)
+    const int r_max = low_bits < 16 ? low_bits : 16;            // at most 65536 passes
+    u16* const fd = fdir + (u64)bucket * (BINS + 1);
+    auto give_up = [&]() {                                      // (an empty, searchable bucket: see k_bucket_dedup)
+        for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fd[i] = 0;
+        if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[bucket] = 0; }
+    };
+    for (int r = 0;; ++r) {
+        if (r > r_max) { give_up(); return; }
+        const u32 npass = 1u << r;
+        u32 total = 0;
+        bool fits = true;
+        for (u32 p = 0; p < npass; ++p) {
+            for (u32 i = threadIdx.x; i < TBL; i += GASM_WG) { t_key[i] = key_empty<K>(); t_cnt[i] = 0; }
+            for (u32 i = threadIdx.x; i < BINS; i += GASM_WG) s_start[i] = 0;
+            if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }
+            __syncthreads();
+            for (u64 i = threadIdx.x; i < n; i += GASM_WG) {
+                const K key = keys[beg + i];
+                if (kis_filler(key)) continue;
+                if (r && (kfield(key, low_bits - r) & (npass - 1)) != p) continue;
+                if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) break;
+                u32 st = khash(key) >> (32 - LOG_SETS);
+                bool ok = false;
+                for (u32 probe = 0; probe < 8 * NSETS && !ok; ++probe) ok = dedup_step<TBL>(t_key, t_cnt, &s_tmp[4], key, st);
+                if (!ok) s_tmp[5] = 1;
+            }
+            __syncthreads();
+            const u32 d = s_tmp[4];
+            if (s_tmp[5] || d > (u32)LIMIT) { fits = false; break; }            // (the same for every thread)
+            if (total + d > GASM_BUCKET_MAX) { give_up(); return; }
+            // the bins of this sub-range; with more sub-range bits than bin bits several passes share a bin, and the first
+            // of them writes its directory entry
+            u32 lo, hi;
+            if (r <= bin_bits) { lo = p << (bin_bits - r); hi = (p + 1) << (bin_bits - r); }
+            else { lo = p >> (r - bin_bits); hi = (p & ((1u << (r - bin_bits)) - 1u)) ? lo : lo + 1; }
+            dedup_order<K, TBL, false, true>(t_key, t_cnt, s_start, s_cur, s_tmp, fdir, bucket, low_bits, d, total, lo, hi);
+            for (u32 i = threadIdx.x; i < d; i += GASM_WG) { keys_out[beg + total + i] = t_key[i]; mult[beg + total + i] = t_cnt[i]; }
+            total += d;
+            __syncthreads();
+        }
+        if (!fits) { __syncthreads(); continue; }
+        // bins no key can fall into (fewer than nine bits below the prefix), and the end of the directory
+        for (u32 i = (1u << bin_bits) + threadIdx.x; i <= (u32)BINS; i += GASM_WG) fd[i] = (u16)total;
+        if (threadIdx.x == 0) bucket_d[bucket] = total;
+        return;
+    }
+}
+template __global__ void k_bucket_dedup_multi<u64>(const u64*, u64*, u32*, const u64*, u32*, u32*, u16*, int);
+template __global__ void k_bucket_dedup_multi<K128>(const K128*, K128*, u32*, const u64*, u32*, u32*, u16*, int);
+
 // Gather the per-bucket distinct runs into the dense per-segment arrays.
 template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const K* __restrict__ keys, const u32* __restrict__ mult,

@@ -61,6 +61,7 @@ struct BuildState {
     int k = 0, bbits = 0, fbits = 9, words = 1, bb_cap = 0;
     bool small_tbl = true;                  // 2048-slot de-duplication tables (else 4096)
     bool rank_global = false;               // list ranking by whole-GPU pointer doubling only (set after the LDS ranking gave up)
+    bool multi_pass = false;                // de-duplication in passes over key sub-ranges (set after the bucket bits ran out: k_bucket_dedup_multi)
     bool ranked_in_lds = false;
     u32 tile_g = 1;                         // threads per read of the tile kernels
     u64 n_kmers = 0, hint = 0, reads_id = 0;
@@ -83,6 +84,7 @@ struct BuildState {
     std::vector<u32> h_dstart;              // n_segments+1: first distinct k-mer of every segment
     std::vector<u32> h_seg_cstart;          // n_segments+1
     std::vector<u64> h_seg_bstart;          // n_segments+1
+    DBuf d_keys2;                           // output of the multi-pass de-duplication (its passes re-read d_keys)
     DBuf d_keys, d_mult, d_hist, d_toff, d_tcnt, d_fdir, d_bstart, d_bucket_d, d_dstart, d_flags, d_rtab;
     DBuf d_dk_key, d_dk_cnt, d_eflag, d_nxt, d_link, d_clen, d_ecid, d_ecoff;
     DBuf d_seg_cbases, d_seg_cstart, d_seg_bstart, d_c_off, d_contig_ascii;

@@ -379,7 +379,7 @@ PathSet DevPaths::view() const {
 void DevPaths::release() { d_words.release(); d_p_off.release(); d_seg_path_off.release(); d_seg_base_off.release(); }
 
 void BuildState::release() {
-    for (DBuf* b : {&d_keys, &d_mult, &d_hist, &d_toff, &d_tcnt, &d_fdir, &d_bstart, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
+    for (DBuf* b : {&d_keys, &d_keys2, &d_mult, &d_hist, &d_toff, &d_tcnt, &d_fdir, &d_bstart, &d_bucket_d, &d_dstart, &d_flags, &d_dk_key, &d_dk_cnt,
                     &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_rtab, &d_seg_cbases, &d_seg_cstart,
                     &d_seg_bstart, &d_c_off, &d_contig_ascii})
         b->release();
@@ -414,7 +414,7 @@ static int ensure_lds_attrs(gasm_ctx* ctx) {
 
 // upper bound of the distinct k-mers of the segments, given the partition: a bucket holds at most `limit` (else it overflows)
 void distinct_caps(BuildState& bs, u32 S) {
-    const u64 limit = bs.small_tbl ? GASM_TBL_LIMIT / 2 : GASM_TBL_LIMIT;
+    const u64 limit = bs.multi_pass ? GASM_BUCKET_MAX : bs.small_tbl ? GASM_TBL_LIMIT / 2 : GASM_TBL_LIMIT;
     const u64 per_seg = ((u64)1 << bs.bbits) * limit;
     const u64 all = bs.k < 16 ? ((u64)1 << (2 * bs.k)) : ~(u64)0;     // 4^k different k-mers exist
     bs.D_cap = 0; bs.maxD_cap = 0;
@@ -497,10 +497,19 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
         d_stamps = stamp_buf.as<unsigned long long>();
     }
     const int dbg_d = knobs().dbg_dedup | (knobs().dedup_warm << 2);
-    bs.fbits = bs.small_tbl ? 9 : 10;   // bins of the de-duplication kernel's counting sort = TBL / 4
+    bs.fbits = (bs.small_tbl && !bs.multi_pass) ? 9 : 10;   // bins of the de-duplication kernel's counting sort = TBL / 4 (the multi-pass kernel: 4096 slots)
     GCHK(bs.d_fdir.ensure((size_t)nbt * ((1u << bs.fbits) + 1) * 2));
     // (k_bucket_dedup writes every entry of its bucket's fine directory)
-    if (W == 2) {
+    if (bs.multi_pass) {
+        // passes over key sub-ranges, for buckets no table can hold; they re-read the bucket, so the result goes to a second
+        // array and is copied back
+        GCHK(bs.d_keys2.ensure(n_alloc * KB));
+        if (W == 2) GLAUNCH(ctx, "k_bucket_dedup_multi", k_bucket_dedup_multi<K128>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_keys2.as<K128>(),
+                            bs.d_mult.as<u32>(), bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits);
+        else GLAUNCH(ctx, "k_bucket_dedup_multi", k_bucket_dedup_multi<u64>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_keys2.as<u64>(),
+                     bs.d_mult.as<u32>(), bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits);
+        HIPCHK(hipMemcpyAsync(bs.d_keys.p, bs.d_keys2.p, n_alloc * KB, hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (W == 2) {
         GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<K128, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
                 bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
     } else if (bs.small_tbl) {
@@ -701,6 +710,7 @@ int plan_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs) {
         bs.maxD_est = (u32)std::min<u64>(dest, 0xFFFFFFF0ull);
         bs.have_actual = false;
         bs.rank_global = false;
+        bs.multi_pass = false;
     }   // else: the same reads again — the partition that worked and the sizes the last build reported
     GCHK(bs.d_flags.ensure(256));      // [0] bucket overflow, [1] list ranking gave up, [16..] the list-ranking launches' "still active" words
     bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
@@ -759,12 +769,11 @@ int pipeline_build_finish_n(gasm_ctx* ctx, DevReads* rd, u32 S, BuildState& bs, 
         if (overflow) {
             if (!rd) { gasm_set_error("a merged k-mer bucket overflowed its table: the pooled build needs more bucket bits"); return GASM_ERR_CAPACITY; }
             if (bs.small_tbl && bs.words == 1) bs.small_tbl = false;      // same partition, larger tables
+            else if (bs.bbits < bs.bb_cap) bs.bbits = std::min(bs.bb_cap, bs.bbits + 2);
+            else if (!bs.multi_pass) bs.multi_pass = true;                // all bucket bits used: key sub-ranges, pass by pass
             else {
-                if (bs.bbits >= bs.bb_cap) {
-                    gasm_set_error("a k-mer bucket holds more than %d distinct k-mers even with %d bucket bits", GASM_TBL_LIMIT, bs.bbits);
-                    return GASM_ERR_CAPACITY;
-                }
-                bs.bbits = std::min(bs.bb_cap, bs.bbits + 2);
+                gasm_set_error("a k-mer bucket holds more than %d distinct k-mers even with %d bucket bits", GASM_BUCKET_MAX, bs.bbits);
+                return GASM_ERR_CAPACITY;
             }
             distinct_caps(bs, S);
             GCHK(launch_distinct(ctx, *rd, bs));

@@ -155,6 +155,29 @@ def test_overflow_retry_and_skewed_bins():
             b.close()
 
 
+def test_buckets_no_table_can_hold():
+    """Skewed base composition (3 C : 1 A): with all ten bucket bits used, the bucket of the prefix CCCCC still holds more
+    distinct k-mers than a table takes (1408 of 128-bit keys, 2816 of 64-bit keys) -> the last rung of the retry ladder,
+    k_bucket_dedup_multi (passes over key sub-ranges).  Contigs, distinct k-mers and multiplicities against the oracle."""
+    rng = np.random.default_rng(2024)
+    for k, rl, L, cov in [(45, 120, 12000, 10), (31, 100, 30000, 8), (63, 150, 9000, 8)]:
+        g = np.frombuffer(b"CCCA", dtype=np.uint8)[rng.integers(0, 4, L)]
+        reads = synth.simulate_reads(g, rl, cov, 11)
+        seg_off = np.array([0, reads.shape[0]], dtype=np.uint64)
+        rs = _strs(reads)
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+        top = max(np.unique([x[:5] for x in ref["distinct"]], return_counts=True)[1])
+        assert top > (2816 if k <= 31 else 1408), (k, top)        # the case really needs the fallback
+        b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+        b.build(k, genome_len_hint=L)
+        assert b.contigs(0) == ref["contigs"], k
+        dk, dm = b.distinct_kmers(0)
+        assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist(), k
+        b.build(k, genome_len_hint=L)                               # again: the partition that worked is kept
+        assert b.contigs(0) == ref["contigs"], k
+        b.close()
+
+
 def test_high_multiplicity_and_homopolymers(qtable):
     """tandem repeats and homopolymer runs: one k-mer thousands of times in a bucket (same-address LDS atomics), nodes with
     self-loops, reads that are all the same string"""

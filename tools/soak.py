@@ -39,10 +39,11 @@ while time.time() - t0 < budget:
         off.append(off[-1] + r.shape[0])
     reads = np.concatenate(parts, axis=0)
     seg_off = np.array(off, dtype=np.uint64)
+    tag = f"S={S} L={L} k={k} rl={rl} cov={cov:.1f} planted={planted} alphabet={alphabet} hint={hint}"
+    print(f"[{time.time() - t0:6.1f} s] batch {rounds + 1}: {tag} ...", flush=True)
     b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
     b.build(k, genome_len_hint=hint).score(8, prob)
     contigs, sc = b.contigs(), b.scores()
-    tag = f"S={S} L={L} k={k} rl={rl} cov={cov:.1f} planted={planted} alphabet={alphabet} hint={hint}"
     for s in range(S):
         rs = [x.tobytes().decode() for x in reads[off[s]:off[s + 1]]]
         ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
