@@ -25,12 +25,14 @@ while time.time() - t0 < budget:
     rl = int(rng.integers(k, k + 120))
     cov = float(rng.uniform(3, 40))
     planted = bool(rng.integers(0, 2))
-    alphabet = rng.choice(["ACGT", "ACGT", "ACGT", "AC", "ACG"])
+    alphabet = rng.choice(["ACGT", "ACGT", "ACGT", "AC", "ACG", "CCCA", "AAAAAAAC", "ACGTTTTTTT"])     # (the long ones: skewed composition)
     hint = int(rng.choice([0, L, max(1, L // 7)]))
     genomes, parts, off = [], [], [0]
     for s in range(S):
         g = synth.make_segment(int(rng.integers(1 << 30)), L, planted=planted)
-        if alphabet != "ACGT":
+        if len(alphabet) > 4:
+            g = np.frombuffer(alphabet.encode(), dtype=np.uint8)[rng.integers(0, len(alphabet), L)]
+        elif alphabet != "ACGT":
             lut = np.frombuffer(alphabet.encode(), dtype=np.uint8)
             g = lut[np.frombuffer(g.tobytes(), dtype=np.uint8) % len(lut)]
         r = synth.simulate_reads(g, rl, cov, int(rng.integers(1 << 30)))
