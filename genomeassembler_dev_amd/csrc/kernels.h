@@ -83,7 +83,7 @@ struct PathSet {
 __global__ void k_pack_ascii(const u8* ascii, u64 nbases_host, const u64* nbases_dev, u64* words, u32* err);
 #define GASM_TILE_WG 512     // threads of a tile workgroup (k_tile_hist, k_bucket_scatter)
 template <class K> __global__ void k_tile_hist(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 n_tiles, ushort4* tcnt);
-__global__ void k_tile_scan(ReadSet rs, int bbits, u32 padm, const ushort4* tcnt, u32* toff, u32* hist);
+__global__ void k_tile_scan(ReadSet rs, int bbits, u32 padm, const ushort4* tcnt, u32* toff, u32* hist, u32* flags);
 template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
 __global__ void k_seg_offsets(const u32* seg_ncontig, const u64* seg_cbases, u32 S, u32* seg_cstart, u64* seg_bstart, const u32* dstart, u32 nb,
                               const u32* flags, u32* report, u32 ticket);
@@ -99,7 +99,8 @@ __global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, u32* bucke
 template <class K>
 __global__ void k_bucket_dedup_multi(const K* keys, K* keys_out, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits);
 template <class K>
-__global__ void k_bucket_gather(const K* keys, const u32* mult, const u64* bstart, const u32* dstart, K* dk_key, u32* dk_cnt, u32* claim, u8* eflag);
+__global__ void k_bucket_gather(const K* keys, const u32* mult, const u64* bstart, const u32* dstart, K* dk_key, u32* dk_cnt, u32* claim, u8* eflag,
+                                u32* flags);
 template <class K> __global__ void k_edge_target(GraphView gv, u32 n_segments, u32 chunks, u32* tgt, u32* claim);
 __global__ void k_edge_multi(GraphView gv, u32 n_segments, u32 chunks, const u32* tgt, const u32* claim, u8* eflag);
 template <class K>

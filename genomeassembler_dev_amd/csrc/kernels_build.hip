@@ -149,9 +149,11 @@ template __global__ void k_tile_hist<K128>(ReadSet, const uint4*, int, int, u32,
 // so that no cache line is written by two workgroups: partial-line writes cost more than half the store bandwidth.
 __device__ __forceinline__ u32 sub_total(ushort4 c) { return (u32)c.x + c.y + c.z + c.w; }
 __global__ void __launch_bounds__(1024) k_tile_scan(ReadSet rs, int bbits, u32 padm, const ushort4* __restrict__ tcnt,
-                                                    u32* __restrict__ toff, u32* __restrict__ hist) {
+                                                    u32* __restrict__ toff, u32* __restrict__ hist, u32* __restrict__ flags) {
     __shared__ u32 s_part[1024];
     const u32 nb = 1u << bbits, seg = blockIdx.x;
+    // the build's 64 flag words start at zero (a fill would be a launch of its own; the first writer is k_bucket_dedup)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) flags[threadIdx.x] = 0;
     const u32 t0 = rs.seg_tile_start[seg], t1 = rs.seg_tile_start[seg + 1];
     // a workgroup = 32 buckets (blockIdx.y) x 32 slices of the segment's tile range: slice sums first, then the offsets
     const u32 nbw = min(nb, 32u), grp = 1024u / nbw, sl = threadIdx.x / nbw, bl = threadIdx.x % nbw;
@@ -771,8 +773,11 @@ template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const K* __restrict__ keys, const u32* __restrict__ mult,
                                                            const u64* __restrict__ bstart, const u32* __restrict__ dstart,
                                                            K* __restrict__ dk_key, u32* __restrict__ dk_cnt, u32* __restrict__ claim,
-                                                           u8* __restrict__ eflag) {
+                                                           u8* __restrict__ eflag, u32* __restrict__ flags) {
     const u32 bucket = blockIdx.x;
+    // the graph kernels' flags — [1] ranking gave up, [16..] "still active" words of the k_link_jump launches — start at
+    // zero; [0], the de-duplication's overflow flag, stays
+    if (bucket == 0 && threadIdx.x >= 1 && threadIdx.x < 64) flags[threadIdx.x] = 0;
     const u64 src = bstart[bucket];
     const u32 dst = dstart[bucket], d = dstart[bucket + 1] - dst;
     for (u32 i = threadIdx.x; i < d; i += GASM_WG) {
@@ -782,8 +787,8 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_gather(const K* __restrict__
         eflag[dst + i] = 0;
     }
 }
-template __global__ void k_bucket_gather<u64>(const u64*, const u32*, const u64*, const u32*, u64*, u32*, u32*, u8*);
-template __global__ void k_bucket_gather<K128>(const K128*, const u32*, const u64*, const u32*, K128*, u32*, u32*, u8*);
+template __global__ void k_bucket_gather<u64>(const u64*, const u32*, const u64*, const u32*, u64*, u32*, u32*, u8*, u32*);
+template __global__ void k_bucket_gather<K128>(const K128*, const u32*, const u64*, const u32*, K128*, u32*, u32*, u8*, u32*);
 
 // ================================================================================================================
 // Graph over the sorted distinct k-mers (= distinct edges) of each segment.  Edge i: key = x·M·y, source node

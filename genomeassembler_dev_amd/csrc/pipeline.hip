@@ -463,7 +463,7 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
     GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
     GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
     GCHK(bs.d_dstart.ensure(((size_t)nbt + 2) * 4));
-    HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 256, ctx->stream));
+    // (d_flags is zeroed by k_tile_scan)
     if (W == 1) {
         GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
                 bs.d_tcnt.as<ushort4>());
@@ -472,7 +472,7 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
                 bs.d_tcnt.as<ushort4>());
     }
     GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S, std::max(1u, nb / 32u)), dim3(1024), 0, rs, bbits, padm, bs.d_tcnt.as<ushort4>(),
-            bs.d_toff.as<u32>(), bs.d_hist.as<u32>());
+            bs.d_toff.as<u32>(), bs.d_hist.as<u32>(), bs.d_flags.as<u32>());
     GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
     const size_t lds = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (GASM_TILE_WG / 8) * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
     // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
@@ -563,15 +563,15 @@ int launch_graph(gasm_ctx* ctx, u32 S, BuildState& bs) {
     const int W = bs.words, bbits = bs.bbits;
     const u32 nb = 1u << bbits, nbt = S * nb;
     GCHK(alloc_graph(bs, S));
-    // the ranking's failure flag and the "still active" words of the k_link_jump launches (the overflow flag [0] stays)
-    HIPCHK(hipMemsetAsync(bs.d_flags.as<u32>() + 1, 0, 252, ctx->stream));
+    // (k_bucket_gather zeroes the ranking's failure flag and the "still active" words of the k_link_jump launches; the
+    // overflow flag [0] stays)
     u32* const d_claim = bs.d_nxt.as<u32>();      // claim words of the degree kernels live in nxt until k_edge_next overwrites them
     if (W == 1) {
         GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<u64>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<u64>(), bs.d_dk_cnt.as<u32>(), d_claim, bs.d_eflag.as<u8>());
+                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<u64>(), bs.d_dk_cnt.as<u32>(), d_claim, bs.d_eflag.as<u8>(), bs.d_flags.as<u32>());
     } else {
         GLAUNCH(ctx, "k_bucket_gather", k_bucket_gather<K128>, dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<K128>(), bs.d_dk_cnt.as<u32>(), d_claim, bs.d_eflag.as<u8>());
+                bs.d_bstart.as<u64>(), bs.d_dstart.as<u32>(), bs.d_dk_key.as<K128>(), bs.d_dk_cnt.as<u32>(), d_claim, bs.d_eflag.as<u8>(), bs.d_flags.as<u32>());
     }
     return launch_graph_dense(ctx, S, bs);
 }
