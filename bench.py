@@ -141,7 +141,7 @@ def main():
             pooled.pooled_build(comm, {rank: be}, n_global, k, args.bbits, kmer=8, table=table, stats=stats)
         return be, step, stats, n_km, int(off[-1])
 
-    dominant = ("k_bucket_scatter", "k_bucket_dedup")
+    dominant = ("k_bucket_partition", "k_bucket_scatter", "k_bucket_dedup")   # (partition: one pass; scatter: its two-pass form)
     profiled = dominant + ("k_score_reads_graph",)
     reads = seg_off = batch = None
     if args.mode == "segments":
@@ -154,6 +154,10 @@ def main():
         def step():
             batch.build(k, genome_len_hint=L)
             batch.score(8, table)
+        # one untimed build whose report is read before anything is timed: a batch whose buckets outgrow the single-pass
+        # partition's regions (or its tables) settles on the configuration that works here, not inside the timed steps
+        step()
+        batch.distinct()
         dt, prof = timed(step, args.steps, args.warmup, profile=profiled)
         seg, keys, mult, _w = batch.distinct()
         n_distinct = int(seg[-1])
@@ -173,6 +177,7 @@ def main():
     alg_bytes = {
         # read packed bases 0.25*rl/(rl-k+1) B per k-mer + write the W-byte key to its bucket
         "k_bucket_scatter": n_kmers * (key_bytes + 0.25 * rl / (rl - k + 1)),
+        "k_bucket_partition": n_kmers * (key_bytes + 0.25 * rl / (rl - k + 1)),
         # read the key back (W bytes per k-mer) + write (key, multiplicity) per distinct k-mer
         "k_bucket_dedup": n_kmers * key_bytes + n_distinct * (key_bytes + 4.0),
     }

@@ -92,8 +92,11 @@ template <class K>
 __global__ void k_bucket_scatter(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 padm, u32 n_tiles, const u64* bstart, const u32* toff,
                                  const ushort4* tcnt, K* keys, u64 scratch);
 #define GASM_RT_MAX 16      // rounds (read groups x offset rounds) one scatter tile may hold
+template <class K>
+__global__ void k_bucket_partition(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 padm, u32 n_tiles, const u64* bstart, u32* cursor,
+                                   K* keys, u64 scratch, u32* flags);
 template <class K, int TBL>
-__global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits, int dbg,
+__global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, const u32* blen, u32* bucket_d, u32* overflow, u16* fdir, int low_bits, int dbg,
                                unsigned long long* stamps);
 #define GASM_BUCKET_MAX 65535   // distinct keys of one bucket (16-bit fine directory)
 template <class K>

@@ -418,6 +418,150 @@ template __global__ void k_bucket_scatter<u64>(ReadSet, const uint4*, int, int, 
 template __global__ void k_bucket_scatter<K128>(ReadSet, const uint4*, int, int, u32, u32, u32, const u64*, const u32*, const ushort4*, K128*, u64);
 
 // ================================================================================================================
+// Single-pass partition: k_tile_hist + k_tile_scan + k_scan_excl + k_bucket_scatter in one kernel.
+//
+// The two-pass form above needs every (tile, bucket) count before the first key moves — a second pass over the reads that
+// does nothing but count (2·10^8 LDS atomics for cfg2: 0.07 ms, plus two scans).  Here every (segment, bucket) owns a
+// region of fixed capacity (bstart[gb] .. bstart[gb + 1], sized by the host from the segment's k-mer count with some room
+// to spare) and a cursor; a tile counts its k-mers per bucket in LDS — the ds_add_rtn that counts IS the rank of the k-mer
+// in its (bucket, sub-counter) — then reserves its line-padded runs with one global atomic per bucket and flushes whole
+// lines as before.  Runs of a bucket therefore lie in the order the tiles got there, which the de-duplication does not
+// care about (its result is ordered and counted).  cursor[gb] ends up as the bucket's padded length (what `hist` is in the
+// two-pass form).  A run that does not fit its region goes to the scratch line, bit 1 of flags[0] is raised, the
+// de-duplication leaves such a bucket empty, and pipeline_build_finish repeats the build with the two-pass kernels.
+// Memory operations of a wave: [next tile's words, region bounds] [cursor atomic: wave(s) of the bucket threads]
+// [NFL stores]; the atomic's value is used before the flush, so the wait at the top stays "all but the NFL stores".
+// LDS: staging as above + nb * 40 + 80 bytes: two workgroups per CU up to 256 buckets.
+// ================================================================================================================
+template <class K>
+__global__ void __launch_bounds__(GASM_TILE_WG, 4) k_bucket_partition(ReadSet rs, const uint4* __restrict__ tinfo, int k, int bbits, u32 g, u32 padm,
+                                                                    u32 n_tiles, const u64* __restrict__ bstart, u32* __restrict__ cursor,
+                                                                    K* __restrict__ keys, u64 scratch, u32* __restrict__ flags) {
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    constexpr u32 KT = KeyTraits<K>::KT;
+    constexpr u32 NFL = KeyTraits<K>::NFL;
+    constexpr u32 KPU = 16 / sizeof(K);
+    constexpr u32 CAP = NFL * GASM_TILE_WG * KPU;
+    const u32 nb = 1u << bbits;                                               // <= GASM_TILE_WG: one bucket per thread
+    const u32 tid = threadIdx.x, wv = tid >> 6, ln = tid & 63, sub = tid & 3u;
+    K* s_key = reinterpret_cast<K*>(s_raw);                                  // CAP + eight trash slots per wave
+    u64* s_comb = reinterpret_cast<u64*>(s_key + CAP + GASM_TILE_WG / 8);    // nb
+    u32* s_base = reinterpret_cast<u32*>(s_comb + ((nb + 1) & ~1u));         // 4 per bucket: staging index of rank 0 of every sub-counter
+    u32* s_cnt = s_base + 4 * nb + 4;                                        // 4 per bucket (sub-counters) + dummy bin; 16-byte aligned
+    u32* s_tmp = s_cnt + 4 * nb + 4;                                         // 12
+    const int bshift = 2 * k - bbits;
+
+    const u32 per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const u32 tile_end = min(n_tiles, (blockIdx.x + 1) * per_wg);
+    u32 tile = blockIdx.x * per_wg;
+    if (tile >= tile_end) return;
+    for (u32 e = tid; e < 4 * nb + 4; e += GASM_TILE_WG) s_cnt[e] = 0;
+
+    Roll<K> rl;
+    u32 nv;
+    auto fetch = [&](const TileInfo& t) { tile_fetch<K>(rs, t, g, k, rl, nv); };
+    TileInfo ti = tile_decode(tinfo, tile);
+    fetch(ti);
+    rl.template wait_all_but<0>();
+    __syncthreads();
+    for (;;) {
+        // ---- count = rank
+        const auto w = rl.prep();
+        const u32 nv_now = nv;
+        const u32 seg = ti.seg;
+        // (the keys themselves are taken from the window again when they are staged — two funnel shifts each — rather than
+        // kept in 32 registers across the two barriers: with them the kernel does not fit the 128 registers of two workgroups per CU)
+        u32 idx[KT];
+        static_for<KT>([&](auto J) {
+            constexpr u32 j = J;
+            const u32 bkt = bbits ? w.template top_hi<j>() >> (32 - bbits) : 0u;
+            idx[j] = atomicAdd(&s_cnt[j < nv_now ? 4 * bkt + sub : 4 * nb], 1u);
+        });
+        // ---- the next tile's inputs, requested ahead of this tile's stores (the last tile re-requests its own)
+        const u32 tnext = tile + 1 < tile_end ? tile + 1 : tile;
+        const TileInfo tin = tile_decode(tinfo, tnext);
+        fetch(tin);
+        __syncthreads();
+        // ---- staging ranges of the buckets, and the reservation of their runs.  `t` is the thread index again, opaque to
+        // the compiler: everything a bucket thread addresses through it (counters, bases, cursor, region, scratch line) is then
+        // computed here, a few instructions per tile, instead of being kept in ~20 registers over the whole loop — which
+        // spilled, and a spill reload is a vector-memory load: its wait also waits for the next tile's words and the stores
+        u32 t = tid, zero = 0;
+        __asm__ volatile("" : "+v"(t), "+v"(zero));
+        u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (t < nb) {
+            const uint4 c = *reinterpret_cast<const uint4*>(&s_cnt[4 * t]);
+            c0 = c.x; c1 = c.y; c2 = c.z; c3 = c.w;
+        }
+        const u32 cnt = c0 + c1 + c2 + c3, padc = (cnt + padm) & ~padm;
+        u32 total;
+        const u32 soff = block_excl_scan<GASM_TILE_WG>(padc, s_tmp, &total);
+        u32 run = 0;
+        u64 beg = 0, end = 0;                      // the region of bucket `tid` (a few KB of directory per segment: L2 hits, used after the staging)
+        if (t < nb) {
+            const u32 gb = seg * nb + t;
+            if (padc) run = atomicAdd(&cursor[gb], padc);
+            beg = bstart[gb]; end = bstart[gb + 1];
+            *reinterpret_cast<uint4*>(&s_base[4 * t]) = make_uint4(soff, soff + c0, soff + c0 + c1, soff + c0 + c1 + c2);
+            *reinterpret_cast<uint4*>(&s_cnt[4 * t]) = make_uint4(zero, zero, zero, zero);
+            for (u32 i = cnt; i < padc; ++i) s_key[soff + i] = key_filler<K>(t, bshift);
+        }
+        __syncthreads();
+        // ---- stage
+        {
+            // (in place: the rank becomes the staging index; the bucket is taken from the window again — keeping the 16 slots
+            // beside the 16 ranks is what pushed the kernel over its registers.  A start past the read's end: trash slot)
+            static_for<KT>([&](auto J) {
+                constexpr u32 j = J;
+                const u32 bkt = bbits ? w.template top_hi<j>() >> (32 - bbits) : 0u;
+                idx[j] += s_base[4 * bkt + sub];
+            });
+            const u32 trash = CAP + wv * 8 + (ln & 7u);
+            static_for<KT>([&](auto J) {
+                constexpr u32 j = J;
+                s_key[j < nv_now ? idx[j] : trash] = w.template key<j>(k);
+            });
+        }
+        if (t < nb) {
+            const bool fits = (u64)run + padc <= end - beg;
+            s_comb[t] = fits ? beg + run - soff : ~0ull;        // staging index i goes to keys[s_comb[bucket] + i]
+            if (!fits) atomicOr(flags, 2u);
+        }
+        __syncthreads();
+        const u64 my_scratch = scratch + (u64)(((blockIdx.x & 1023u) * (GASM_TILE_WG / 64)) * 64 + t) * KPU;   // (wave * 64 + lane = t)
+        // ---- stream out (as k_bucket_scatter; a run without room goes to the scratch line)
+        static_assert(NFL % 3 == 0, "flush passes come in threes");
+#pragma unroll
+        for (u32 u0 = 0; u0 < NFL; u0 += 3) {
+            u64x2 wd[3];
+            u64 cb[3];
+#pragma unroll
+            for (u32 u = 0; u < 3; ++u) wd[u] = *reinterpret_cast<const u64x2*>(s_key + (t + GASM_TILE_WG * (u0 + u)) * KPU);
+#pragma unroll
+            for (u32 u = 0; u < 3; ++u) {
+                u32 bkt = 0;
+                if (bbits) {
+                    if constexpr (KPU == 2) bkt = (u32)(wd[u].x >> bshift) & (nb - 1);
+                    else bkt = kfield(K128{wd[u].x, wd[u].y}, bshift) & (nb - 1);
+                }
+                cb[u] = s_comb[bkt];
+            }
+#pragma unroll
+            for (u32 u = 0; u < 3; ++u) {
+                const u32 i = (t + GASM_TILE_WG * (u0 + u)) * KPU;
+                *reinterpret_cast<u64x2*>(keys + ((i < total && cb[u] != ~0ull) ? cb[u] + i : my_scratch)) = wd[u];
+            }
+        }
+        if (++tile >= tile_end) break;
+        __syncthreads();          // staging is free again
+        ti = tin;
+        rl.template wait_all_but<NFL>();
+    }
+}
+template __global__ void k_bucket_partition<u64>(ReadSet, const uint4*, int, int, u32, u32, u32, const u64*, u32*, u64*, u64, u32*);
+template __global__ void k_bucket_partition<K128>(ReadSet, const uint4*, int, int, u32, u32, u32, const u64*, u32*, K128*, u64, u32*);
+
+// ================================================================================================================
 // De-duplicate one bucket: stream its keys through an LDS table (count per distinct key), then order the distinct keys
 // and write them and their multiplicities back over the start of the bucket's own range.
 //
@@ -511,7 +655,7 @@ __device__ __forceinline__ bool dedup_step(K128* t_key, u32* t_cnt, u32* n_disti
 #endif
 template <class K, int TBL>
 __global__ void __launch_bounds__(GASM_WG, TBL == 4096 ? 3 : sizeof(K) == 8 ? GASM_DEDUP_WGS : 4)
-k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
+k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restrict__ bstart, const u32* __restrict__ blen, u32* __restrict__ bucket_d,
                u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg, unsigned long long* __restrict__ stamps) {
     constexpr int LIMIT = TBL / 16 * 11;
     constexpr int BINS = TBL / 4;
@@ -549,7 +693,18 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     };
     const u32 bucket = blockIdx.x;
     const u64 beg = bstart[bucket], end = bstart[bucket + 1];
-    const u64 n = end - beg;
+    u64 n = end - beg;
+    if (blen) {
+        // single-pass partition (k_bucket_partition): the bucket's region is [beg, end), its keys the first blen[bucket] of it.
+        // A bucket that outgrew its region lost runs (bit 1 of *overflow is up, the build will be repeated): empty and searchable
+        const u64 len = blen[bucket];
+        if (len > n) {
+            for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)bucket * (BINS + 1) + i] = 0;
+            if (threadIdx.x == 0) bucket_d[bucket] = 0;
+            return;
+        }
+        n = len;
+    }
     const u32 warm = (u32)(dbg >> 2) & 3u;        // iterations taken key by key (64-bit keys)
     for (u32 i = threadIdx.x; i < TBL; i += GASM_WG) { t_key[i] = key_empty<K>(); t_cnt[i] = 0; }
     if (!WIDE && threadIdx.x == 0) { *w_distinct = 0; *w_overflow = 0; s_tmp[6] = 0; }   // ([6] longest bin: dedup_order zeroes it when the bins live in the table)
@@ -678,7 +833,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
         // kernels of THIS attempt run (pipeline_build_finish), so the bucket must be left empty AND searchable: an all-zero
         // fine directory (graph_lower_bound would otherwise bisect between whatever the allocation held)
         for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)bucket * (BINS + 1) + i] = 0;
-        if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[bucket] = 0; }
+        if (threadIdx.x == 0) { atomicOr(overflow, 1u); bucket_d[bucket] = 0; }
         return;
     }
     const u32 d = *w_distinct;
@@ -690,9 +845,9 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     phase(5);
     if (stamps && threadIdx.x == 0) stamps[8 + 3 * (u64)blockIdx.x + 1] = wall_clock64();
 }
-template __global__ void k_bucket_dedup<u64, 4096>(u64*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
-template __global__ void k_bucket_dedup<u64, 2048>(u64*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
-template __global__ void k_bucket_dedup<K128, 2048>(K128*, u32*, const u64*, u32*, u32*, u16*, int, int, unsigned long long*);
+template __global__ void k_bucket_dedup<u64, 4096>(u64*, u32*, const u64*, const u32*, u32*, u32*, u16*, int, int, unsigned long long*);
+template __global__ void k_bucket_dedup<u64, 2048>(u64*, u32*, const u64*, const u32*, u32*, u32*, u16*, int, int, unsigned long long*);
+template __global__ void k_bucket_dedup<K128, 2048>(K128*, u32*, const u64*, const u32*, u32*, u32*, u16*, int, int, unsigned long long*);
 
 // ================================================================================================================
 // De-duplication of buckets that no table can hold (the last rung of pipeline_build_finish's ladder: ten bucket bits and
@@ -722,7 +877,7 @@ __global__ void __launch_bounds__(GASM_WG) k_bucket_dedup_multi(const K* __restr
     u16* const fd = fdir + (u64)bucket * (BINS + 1);
     auto give_up = [&]() {                                      // (an empty, searchable bucket: see k_bucket_dedup)
         for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fd[i] = 0;
-        if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[bucket] = 0; }
+        if (threadIdx.x == 0) { atomicOr(overflow, 1u); bucket_d[bucket] = 0; }
     };
     for (int r = 0;; ++r) {
         if (r > r_max) { give_up(); return; }

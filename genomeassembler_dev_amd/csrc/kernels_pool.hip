@@ -108,7 +108,7 @@ k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, co
             const u64 off = n_nonempty ? run_off[(u64)j * n_src + only] : 0ull;
             if (len > (u32)LIMIT) {
                 for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)j * (BINS + 1) + i] = 0;
-                if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[j] = 0; }
+                if (threadIdx.x == 0) { atomicOr(overflow, 1u); bucket_d[j] = 0; }
                 return;
             }
             const u64 beg = bstart[j];
@@ -147,7 +147,7 @@ k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, co
     __syncthreads();
     if (s_tmp[5] || s_tmp[4] > (u32)LIMIT) {
         for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)j * (BINS + 1) + i] = 0;      // empty and searchable
-        if (threadIdx.x == 0) { atomicExch(overflow, 1u); bucket_d[j] = 0; }
+        if (threadIdx.x == 0) { atomicOr(overflow, 1u); bucket_d[j] = 0; }
         return;
     }
     const u32 d = s_tmp[4];

@@ -61,6 +61,12 @@ struct BuildState {
     int k = 0, bbits = 0, fbits = 9, words = 1, bb_cap = 0;
     bool small_tbl = true;                  // 2048-slot de-duplication tables (else 4096)
     bool rank_global = false;               // list ranking by whole-GPU pointer doubling only (set after the LDS ranking gave up)
+    bool single_pass = true;                // partition in one pass into regions of fixed capacity (k_bucket_partition); cleared when a region overflowed
+    // the region layout in d_bstart belongs to ... (uploaded once per batch shape)
+    bool part_valid = false;
+    u64 part_reads_id = 0, part_alloc = 0;
+    int part_k = 0, part_bbits = 0, part_slack = 0, part_forced = 0;
+    u32 part_padm = 0, part_g = 0;
     bool multi_pass = false;                // de-duplication in passes over key sub-ranges (set after the bucket bits ran out: k_bucket_dedup_multi)
     bool ranked_in_lds = false;
     u32 tile_g = 1;                         // threads per read of the tile kernels

@@ -52,6 +52,10 @@ struct Knobs {
     }
 };
 static const Knobs& knobs() { static const Knobs k; return k; }
+// knobs read at every build (tests switch them inside one process):
+//   GASM_SINGLE_PASS=0     two-pass partition (count, scan, scatter) from the start       GASM_PART_SLACK=percent   room per bucket region (100)
+//   GASM_DBG_PART_CAP=n    force the capacity of every bucket region to n keys (exercises the overflow path)
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 
 // Wait for a report a kernel writes into pinned host memory: the kernel's last store is `ticket` at `word`.  Spinning on
 // that word costs a few microseconds; waking up from hipStreamSynchronize costs 15-20 us (more on a busy host) — twice
@@ -403,6 +407,8 @@ static int ensure_lds_attrs(gasm_ctx* ctx) {
     if (ctx->lds_attrs_set) return GASM_OK;         // per context = per device: the attribute is a property of the device's code object
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_scatter<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_partition<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_partition<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist<u64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_hist<K128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rank_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
@@ -454,44 +460,93 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
     const u32 g = bs.tile_g;
     const u32 grid_tiles = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().hist_wgs);
     constexpr u32 SCRATCH_KEYS = 1024 * (GASM_TILE_WG / 64) * 64 * 2;   // 16 bytes per lane and wave of 1024 workgroup slots (k_bucket_scatter)
-    GCHK(bs.d_hist.ensure((size_t)nbt * 4));
-    GCHK(bs.d_toff.ensure((size_t)rd.n_tiles * nb * 4));
-    const u64 n_alloc = N + (u64)padm * rd.n_tiles * nb;
-    GCHK(bs.d_keys.ensure((n_alloc + SCRATCH_KEYS) * KB));
-    GCHK(bs.d_mult.ensure(n_alloc * 4));
-    GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 8 + 64));      // four 16-bit sub-counts per (tile, bucket)
     GCHK(bs.d_bstart.ensure(((size_t)nbt + 1) * 8));
     GCHK(bs.d_bucket_d.ensure((size_t)nbt * 4));
     GCHK(bs.d_dstart.ensure(((size_t)nbt + 2) * 4));
-    // (d_flags is zeroed by k_tile_scan)
-    if (W == 1) {
-        GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
-                bs.d_tcnt.as<ushort4>());
+    u64 n_alloc;
+    const u32* d_blen = nullptr;              // single pass: the buckets' padded lengths (the partition's cursors)
+    const bool single = bs.single_pass && !bs.multi_pass && nb <= GASM_TILE_WG;
+    if (single) {
+        // ---- one pass (k_bucket_partition): a region of fixed capacity per (segment, bucket) — the segment's k-mers per
+        // bucket with `part_slack` percent to spare, room for Poisson noise and for the padding of its tiles' runs, in whole
+        // lines — and a cursor per region; cursors and the build's flag words are one allocation, zeroed by one fill
+        const int slack = env_int("GASM_PART_SLACK", 100), forced = env_int("GASM_DBG_PART_CAP", 0);
+        const bool same_layout = bs.part_valid && bs.part_reads_id == rd.upload_id && bs.part_k == k && bs.part_bbits == bbits && bs.part_padm == padm &&
+                                 bs.part_g == g && bs.part_slack == slack && bs.part_forced == forced;
+        if (!same_layout) {
+            std::vector<u64> h((size_t)nbt + 1);
+            u64 at = 0;
+            for (u32 s = 0; s < S; ++s) {
+                const u64 mean = ceil_div_u64(bs.h_seg_nk[s], nb), tiles = rd.h_seg_tile_start[s + 1] - rd.h_seg_tile_start[s];
+                u64 cap = mean + (u64)((double)mean * std::max(slack, 0) / 100.0) + (u64)(8.0 * std::sqrt((double)mean)) + 32 + tiles * padm;
+                if (forced > 0) cap = (u64)forced;
+                cap = (cap + line_keys - 1) / line_keys * line_keys;
+                for (u32 b = 0; b < nb; ++b) { h[(size_t)s * nb + b] = at; at += cap; }
+            }
+            h[nbt] = at;
+            bs.part_alloc = at;
+            GCHK(h2d(ctx, bs.d_bstart, h.data(), h.size() * 8));
+            HIPCHK(hipStreamSynchronize(ctx->stream));          // (`h` goes out of scope; only when the batch shape changes)
+            bs.part_valid = true; bs.part_reads_id = rd.upload_id; bs.part_k = k; bs.part_bbits = bbits; bs.part_padm = padm; bs.part_g = g;
+            bs.part_slack = slack; bs.part_forced = forced;
+        }
+        n_alloc = bs.part_alloc;
+        GCHK(bs.d_keys.ensure((n_alloc + SCRATCH_KEYS) * KB));
+        GCHK(bs.d_mult.ensure(n_alloc * 4));
+        GCHK(bs.d_flags.ensure(256 + (size_t)nbt * 4));
+        HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 256 + (size_t)nbt * 4, ctx->stream));
+        u32* const d_cursor = bs.d_flags.as<u32>() + 64;
+        d_blen = d_cursor;
+        const size_t lds = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (GASM_TILE_WG / 8) * KB + (size_t)((nb + 1) & ~1u) * 8 + (size_t)(4 * nb + 4) * 8 + 48;
+        const u32 grid_part = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
+        if (W == 1) {
+            GLAUNCH(ctx, "k_bucket_partition", k_bucket_partition<u64>, dim3(grid_part), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), d_cursor, bs.d_keys.as<u64>(), n_alloc, bs.d_flags.as<u32>());
+        } else {
+            GLAUNCH(ctx, "k_bucket_partition", k_bucket_partition<K128>, dim3(grid_part), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), d_cursor, bs.d_keys.as<K128>(), n_alloc, bs.d_flags.as<u32>());
+        }
     } else {
-        GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
-                bs.d_tcnt.as<ushort4>());
-    }
-    GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S, std::max(1u, nb / 32u)), dim3(1024), 0, rs, bbits, padm, bs.d_tcnt.as<ushort4>(),
-            bs.d_toff.as<u32>(), bs.d_hist.as<u32>(), bs.d_flags.as<u32>());
-    GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
-    const size_t lds = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (GASM_TILE_WG / 8) * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
-    // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
-    const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
-    if (W == 1) {
-        GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
-                bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<u64>(), n_alloc);
-    } else {
-        GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
-                bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<K128>(), n_alloc);
+        // ---- two passes: count, scan, scatter (exact layout; the retry path of the single pass, > 512 buckets, multi-pass builds)
+        bs.part_valid = false;                // (k_scan_excl overwrites d_bstart)
+        GCHK(bs.d_hist.ensure((size_t)nbt * 4));
+        GCHK(bs.d_toff.ensure((size_t)rd.n_tiles * nb * 4));
+        n_alloc = N + (u64)padm * rd.n_tiles * nb;
+        GCHK(bs.d_keys.ensure((n_alloc + SCRATCH_KEYS) * KB));
+        GCHK(bs.d_mult.ensure(n_alloc * 4));
+        GCHK(bs.d_tcnt.ensure((size_t)rd.n_tiles * nb * 8 + 64));      // four 16-bit sub-counts per (tile, bucket)
+        // (d_flags is zeroed by k_tile_scan)
+        if (W == 1) {
+            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<u64>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
+                    bs.d_tcnt.as<ushort4>());
+        } else {
+            GLAUNCH(ctx, "k_tile_hist", k_tile_hist<K128>, dim3(grid_tiles), dim3(GASM_TILE_WG), (size_t)nb * 16, rs, rs.tile_info, k, bbits, g, rd.n_tiles,
+                    bs.d_tcnt.as<ushort4>());
+        }
+        GLAUNCH(ctx, "k_tile_scan", k_tile_scan, dim3(S, std::max(1u, nb / 32u)), dim3(1024), 0, rs, bbits, padm, bs.d_tcnt.as<ushort4>(),
+                bs.d_toff.as<u32>(), bs.d_hist.as<u32>(), bs.d_flags.as<u32>());
+        GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u64>, dim3(1), dim3(1024), 0, bs.d_hist.as<u32>(), bs.d_bstart.as<u64>(), nbt);
+        const size_t lds = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (GASM_TILE_WG / 8) * KB + (size_t)nb * 24 + 96;   // KeyTraits<K>::NFL passes + trash slots + cursors
+        // two workgroups per CU fit (LDS); a few tiles per workgroup so that the prefetch of the next tile pays
+        const u32 grid_scatter = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
+        if (W == 1) {
+            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<u64>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<u64>(), n_alloc);
+        } else {
+            GLAUNCH(ctx, "k_bucket_scatter", k_bucket_scatter<K128>, dim3(grid_scatter), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
+                    bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<K128>(), n_alloc);
+        }
     }
     unsigned long long* d_stamps = nullptr;
     static DBuf stamp_buf;
     if (knobs().stamps) {   // diagnostic: per-phase cycle totals of k_bucket_dedup to stderr
-        int o1 = 0, o2 = 0, o3 = 0;
+        int o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+        const size_t lds_stage = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (GASM_TILE_WG / 8) * KB;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_bucket_dedup<u64, 2048>, GASM_WG, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_bucket_dedup<u64, 4096>, GASM_WG, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, k_bucket_scatter<u64>, GASM_TILE_WG, lds);
-        fprintf(stderr, "[occupancy API] dedup<2048> %d  dedup<4096> %d  scatter %d blocks/CU\n", o1, o2, o3);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o3, k_bucket_scatter<u64>, GASM_TILE_WG, lds_stage + (size_t)nb * 24 + 96);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&o4, k_bucket_partition<u64>, GASM_TILE_WG, lds_stage + (size_t)nb * 40 + 96);
+        fprintf(stderr, "[occupancy API] dedup<2048> %d  dedup<4096> %d  scatter %d  partition %d blocks/CU\n", o1, o2, o3, o4);
         GCHK(stamp_buf.ensure(64 + (size_t)nbt * 24));
         HIPCHK(hipMemsetAsync(stamp_buf.p, 0, 64 + (size_t)nbt * 24, ctx->stream));
         d_stamps = stamp_buf.as<unsigned long long>();
@@ -511,13 +566,13 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
         HIPCHK(hipMemcpyAsync(bs.d_keys.p, bs.d_keys2.p, n_alloc * KB, hipMemcpyDeviceToDevice, ctx->stream));
     } else if (W == 2) {
         GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<K128, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+                bs.d_bstart.as<u64>(), d_blen, bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
     } else if (bs.small_tbl) {
         GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+                bs.d_bstart.as<u64>(), d_blen, bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
     } else {
         GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 4096>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+                bs.d_bstart.as<u64>(), d_blen, bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
     }
     if (d_stamps) {
         std::vector<unsigned long long> hv(8 + (size_t)nbt * 3);
@@ -711,6 +766,7 @@ int plan_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs) {
         bs.have_actual = false;
         bs.rank_global = false;
         bs.multi_pass = false;
+        bs.single_pass = env_int("GASM_SINGLE_PASS", 1) != 0;
     }   // else: the same reads again — the partition that worked and the sizes the last build reported
     GCHK(bs.d_flags.ensure(256));      // [0] bucket overflow, [1] list ranking gave up, [16..] the list-ranking launches' "still active" words
     bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
@@ -763,12 +819,15 @@ int pipeline_build_finish_n(gasm_ctx* ctx, DevReads* rd, u32 S, BuildState& bs, 
         const u32* const rep = bs.h_report;
         GCHK(wait_report(ctx, rep + 4 * (size_t)S + 6, bs.ticket));
         bs.pending = false;
-        const bool overflow = rep[4 * (size_t)S + 4] != 0, rank_failed = rep[4 * (size_t)S + 5] != 0;
+        // flags[0]: bit 0 = a bucket overflowed its table, bit 1 = a bucket outgrew its region (single-pass partition)
+        const bool part_overflow = (rep[4 * (size_t)S + 4] & 2u) != 0;
+        const bool overflow = (rep[4 * (size_t)S + 4] & 1u) != 0 || part_overflow, rank_failed = rep[4 * (size_t)S + 5] != 0;
         if (!overflow && !rank_failed) break;
         if (rebuilt) *rebuilt = true;
         if (overflow) {
             if (!rd) { gasm_set_error("a merged k-mer bucket overflowed its table: the pooled build needs more bucket bits"); return GASM_ERR_CAPACITY; }
-            if (bs.small_tbl && bs.words == 1) bs.small_tbl = false;      // same partition, larger tables
+            if (part_overflow && bs.single_pass) bs.single_pass = false;  // same partition, exact layout (count, scan, scatter)
+            else if (bs.small_tbl && bs.words == 1) bs.small_tbl = false;      // same partition, larger tables
             else if (bs.bbits < bs.bb_cap) bs.bbits = std::min(bs.bb_cap, bs.bbits + 2);
             else if (!bs.multi_pass) bs.multi_pass = true;                // all bucket bits used: key sub-ranges, pass by pass
             else {

@@ -58,7 +58,7 @@ static int read_lens(gasm_pool* p, u32 n) {
     u32 fl[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(fl, p->bs.d_flags.p, 8, hipMemcpyDeviceToHost, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
-    return fl[0] ? 1 : 0;       // 1 = a bucket overflowed its table
+    return (int)(fl[0] & 3u);   // bit 0 = a bucket overflowed its table, bit 1 = a bucket outgrew its region (single-pass partition)
 }
 
 extern "C" {
@@ -106,6 +106,7 @@ int gasm_pool_local_runs(gasm_pool* p, int k, int bbits, const uint32_t** run_le
         GCHK(bs.d_bstart.ensure(((size_t)p->n_runs + 1) * 8));
         GCHK(bs.d_keys.ensure(64)); GCHK(bs.d_mult.ensure(64));
         HIPCHK(hipMemsetAsync(bs.d_bucket_d.p, 0, (size_t)p->n_runs * 4 + 8, ctx->stream));
+        bs.part_valid = false;
         HIPCHK(hipMemsetAsync(bs.d_bstart.p, 0, ((size_t)p->n_runs + 1) * 8, ctx->stream));
         HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 256, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -120,6 +121,7 @@ int gasm_pool_local_runs(gasm_pool* p, int k, int bbits, const uint32_t** run_le
         const int ov = read_lens(p, p->n_runs);
         if (ov < 0) return ov;
         if (!ov) break;
+        if ((ov & 2) && bs.single_pass) { bs.single_pass = false; continue; }
         if (bs.small_tbl && bs.words == 1) { bs.small_tbl = false; continue; }
         gasm_set_error("a k-mer bucket of this rank holds more than %d distinct k-mers with %d bucket bits", GASM_TBL_LIMIT, bbits);
         return GASM_ERR_CAPACITY;
@@ -179,6 +181,7 @@ int gasm_pool_merge_runs(gasm_pool* p, uint32_t n_out, uint32_t n_src, const uin
     // (the previous runs have been packed and sent: their arrays are overwritten)
     GCHK(bs.d_keys.ensure(std::max<u64>(bstart[n_out], 1) * KB));
     GCHK(bs.d_mult.ensure(std::max<u64>(bstart[n_out], 1) * 4));
+    bs.part_valid = false;                      // (d_bstart no longer holds the partition's region layout)
     GCHK(up(ctx, bs.d_bstart, bstart.data(), bstart.size() * 8));
     GCHK(bs.d_bucket_d.ensure((size_t)n_out * 4 + 8));
     bs.small_tbl = bs.words == 2;               // the merge uses 4096-slot tables for 64-bit keys, 2048-slot ones for 128-bit keys

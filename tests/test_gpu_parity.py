@@ -560,6 +560,30 @@ def test_many_segments_against_oracle(qtable, n_seg, L, rl, cov, k):
     b.close()
 
 
+@pytest.mark.parametrize("mode", ["two_pass", "region_overflow", "tight_regions"])
+@pytest.mark.parametrize("n_seg,L,rl,cov,k", [(12, 6000, 70, 30, 25), (9, 5000, 120, 25, 45)])
+def test_partition_paths_against_oracle(qtable, monkeypatch, mode, n_seg, L, rl, cov, k):
+    """The partition of the k-mers into (segment, bucket) ranges has two forms: one pass into regions of fixed capacity
+    (k_bucket_partition, the default every other test runs) and count + scan + scatter (k_tile_hist, k_tile_scan,
+    k_bucket_scatter: the exact layout).  Here the second one from the start (GASM_SINGLE_PASS=0), regions far too small
+    for their buckets (every run overflows: the build must come back through the two-pass kernels), and regions without
+    room to spare where only some buckets overflow — all against the oracle, 64- and 128-bit keys, built twice."""
+    keys, prob = qtable
+    if mode == "two_pass":
+        monkeypatch.setenv("GASM_SINGLE_PASS", "0")
+    elif mode == "region_overflow":
+        monkeypatch.setenv("GASM_DBG_PART_CAP", "16")
+    reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, cov, seed0=9100 + k, planted=True)
+    if mode == "tight_regions":      # a segment's k-mers per bucket at the five bucket bits these shapes get: about half the regions too small
+        monkeypatch.setenv("GASM_DBG_PART_CAP", str(int(seg_off[1] - seg_off[0]) * (rl - k + 1) // 32))
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    for _ in range(2):
+        b.build(k, genome_len_hint=L).score(8, prob)
+        contigs, sc = _check_batch_properties(b, seg_off, rl, k, n_seg)
+        _check_segments_vs_oracle(b, reads, seg_off, genomes, range(n_seg), k, keys, prob, contigs, sc)
+    b.close()
+
+
 def test_headline_shape_configs2(qtable):
     """BASELINE configs[2] as bench.py runs it: 100 x 50 kb segments, 150 bp reads at 50x, k=31, scoring on all contigs.
     Properties on all 100 segments; the full oracle comparison on segments either side of the 8-segment (XCD) and
