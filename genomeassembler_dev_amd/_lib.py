@@ -95,6 +95,7 @@ SYMBOLS = {
     "gasm_batch_total_reads": (_u64, [_vp]),
     "gasm_batch_fetch_distinct": (_int, [_vp, _PP, _PP, _PP, C.POINTER(_int)]),
     "gasm_batch_fetch_contigs": (_int, [_vp, _PP, _PP, _PP]),
+    "gasm_batch_fetch_graph": (_int, [_vp, _PP, _PP]),
     "gasm_batch_fetch_scores": (_int, [_vp, _PP, _PP, _PP, _PP, _PP]),
     "gasm_pool_create": (_int, [_vp, _vp, _u64, _u32, _vp, _u32, _PP]),
     "gasm_pool_free": (None, [_vp]),

@@ -135,6 +135,19 @@ class SegmentBatch:
         a, b = int(seg[segment]), int(seg[segment + 1])
         return unpack_kmers(keys[a * w:b * w], self.k, w), mult[a:b]
 
+    def graph(self):
+        """(edge_flags uint8, edge_next uint32), one entry per distinct k-mer in the order of distinct(): bit 0 of a flag = the
+        edge's source node is branching, bit 1 (first out-edge of a node) = the node has two or more in-edges; edge_next =
+        the edge the walk continues with, 0xFFFFFFFF at the end of a contig (lib/DeNovoAssembler.cpp:125-189)"""
+        seg = self.distinct()[0]
+        n = int(seg[-1])
+        fl, nx = C.c_void_p(), C.c_void_p()
+        check(lib().gasm_batch_fetch_graph(self.h, C.byref(fl), C.byref(nx)))
+        if not n:
+            return np.zeros(0, np.uint8), np.zeros(0, np.uint32)
+        return (np.ctypeslib.as_array(C.cast(fl, C.POINTER(C.c_uint8)), shape=(n,)).copy(),
+                np.ctypeslib.as_array(C.cast(nx, C.POINTER(C.c_uint32)), shape=(n,)).copy())
+
     def contigs_raw(self):
         """(seg_contig_off[n_segments+1], contig base offsets[n_contigs+1], ASCII bytes)"""
         so, off, data = C.c_void_p(), C.c_void_p(), C.c_void_p()

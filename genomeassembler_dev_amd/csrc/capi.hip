@@ -69,7 +69,8 @@ struct gasm_batch {
     int score_kmer = 0;
     // concatenated host results of the sub-batches (fetch)
     std::vector<u64> h_seg_doff, h_dk_key, h_seg_coff, h_c_off;
-    std::vector<u32> h_dk_cnt;
+    std::vector<u32> h_dk_cnt, h_nxt;
+    std::vector<u8> h_eflag;
     std::vector<char> h_contigs;
     std::vector<double> h_bp, h_nf, h_nl;
     std::vector<int32_t> h_breaks, h_len;
@@ -779,6 +780,28 @@ int gasm_batch_fetch_distinct(gasm_batch* b, const uint64_t** seg_off, const uin
         b->h_dk_cnt.insert(b->h_dk_cnt.end(), sb.bs.h_dk_cnt.begin(), sb.bs.h_dk_cnt.end());
     }
     *seg_off = b->h_seg_doff.data(); *keys = b->h_dk_key.data(); *mult = b->h_dk_cnt.data();
+    return GASM_OK;
+    API_GUARD_END
+}
+
+int gasm_batch_fetch_graph(gasm_batch* b, const uint8_t** edge_flags, const uint32_t** edge_next) {
+    API_GUARD_BEGIN
+    if (!b || !edge_flags || !edge_next) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
+    if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
+    GCHK(batch_finish(b));
+    for (SubBatch& sb : b->sub) GCHK(pipeline_fetch_graph(sb.cx, sb.rd, sb.bs));
+    if (b->sub.size() == 1) {
+        *edge_flags = b->sub[0].bs.h_eflag.data(); *edge_next = b->sub[0].bs.h_nxt.data();
+        return GASM_OK;
+    }
+    b->h_eflag.clear(); b->h_nxt.clear();
+    u32 base = 0;
+    for (SubBatch& sb : b->sub) {
+        b->h_eflag.insert(b->h_eflag.end(), sb.bs.h_eflag.begin(), sb.bs.h_eflag.end());
+        for (u32 v : sb.bs.h_nxt) b->h_nxt.push_back(v == 0xFFFFFFFFu ? v : v + base);
+        base += sb.bs.d_total;
+    }
+    *edge_flags = b->h_eflag.data(); *edge_next = b->h_nxt.data();
     return GASM_OK;
     API_GUARD_END
 }

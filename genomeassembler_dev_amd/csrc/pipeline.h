@@ -96,7 +96,8 @@ struct BuildState {
     DBuf d_seg_cbases, d_seg_cstart, d_seg_bstart, d_c_off, d_contig_ascii;
     // host copies filled by fetch
     std::vector<u64> h_seg_doff, h_dk_key, h_c_off, h_seg_coff;
-    std::vector<u32> h_dk_cnt;
+    std::vector<u32> h_dk_cnt, h_nxt;
+    std::vector<u8> h_eflag;
     std::vector<char> h_contigs;
     bool fetched_distinct = false, fetched_contigs = false;
     void release();
@@ -143,6 +144,7 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs);
 int launch_graph(gasm_ctx* ctx, u32 n_segments, BuildState& bs);
 int pipeline_fetch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs);
 int pipeline_fetch_contigs(gasm_ctx* ctx, DevReads& rd, BuildState& bs);
+int pipeline_fetch_graph(gasm_ctx* ctx, DevReads& rd, BuildState& bs);    // h_eflag / h_nxt: per-edge flags and successors
 // paths of the build as a DevPaths (packs the contig text on the device; works on a queued build); the host-side numbers
 // of the same paths once the build's report has been read
 int pipeline_contig_paths(gasm_ctx* ctx, const DevReads& rd, const BuildState& bs, DevPaths& dp);

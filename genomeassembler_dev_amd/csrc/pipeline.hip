@@ -877,6 +877,19 @@ int pipeline_fetch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
     return GASM_OK;
 }
 
+// per-edge flags and successors of the finished build (rows A4-A6 of SURVEY §8 made visible: lib/DeNovoAssembler.cpp:125-189)
+int pipeline_fetch_graph(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
+    GCHK(pipeline_build_finish(ctx, rd, bs, nullptr));
+    bs.h_eflag.resize(bs.d_total);
+    bs.h_nxt.resize(bs.d_total);
+    if (bs.d_total) {
+        HIPCHK(hipMemcpyAsync(bs.h_eflag.data(), bs.d_eflag.p, (size_t)bs.d_total, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(bs.h_nxt.data(), bs.d_nxt.p, (size_t)bs.d_total * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return GASM_OK;
+}
+
 int pipeline_fetch_contigs(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
     GCHK(pipeline_build_finish(ctx, rd, bs, nullptr));
     if (bs.fetched_contigs) return GASM_OK;

@@ -224,6 +224,12 @@ uint64_t gasm_batch_total_reads(const gasm_batch* b);
 /* results of the last build (host copies, valid until the next build/free) */
 int gasm_batch_fetch_distinct(gasm_batch* b, const uint64_t** seg_off /*n_segments+1*/, const uint64_t** keys,
                               const uint32_t** mult, int* words);
+/* The (k-1)-mer graph of the last build, one entry per distinct k-mer (= distinct edge) in the order of gasm_batch_fetch_distinct:
+ * restates the degree table and the branching-node list of lib/DeNovoAssembler.cpp:125-169 and one step of its walk (:172-189).
+ *   edge_flags bit 0: the edge's source node (its first k-1 bases) is a branching node (in-degree != 1 or out-degree != 1);
+ *              bit 1: (on the first out-edge of a node, in sorted order) the node has two or more in-edges;
+ *   edge_next: the edge the walk continues with (index into the batch's distinct list), 0xFFFFFFFF where a contig ends. */
+int gasm_batch_fetch_graph(gasm_batch* b, const uint8_t** edge_flags, const uint32_t** edge_next);
 int gasm_batch_fetch_contigs(gasm_batch* b, const uint64_t** seg_contig_off /*n_segments+1*/, const uint64_t** off,
                              const char** data);
 /* results of the last score: one entry per contig, in the order of gasm_batch_fetch_contigs */

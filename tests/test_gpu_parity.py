@@ -104,6 +104,48 @@ def test_get_contigs_edge_cases():
     assert m.contigs == [] and m.perm.shape == (4, 0)
 
 
+@pytest.mark.parametrize("k,rl", [(15, 50), (41, 90)])
+def test_graph_degrees_and_branching_nodes_against_oracle(k, rl):
+    """Rows A4-A6 directly (lib/DeNovoAssembler.cpp:125-189), not only through the contigs they lead to: out-degrees (runs of
+    edges sharing a source node), in-degree classes (the claim-word trick: bit 1 of the node's first out-edge <=> two or more
+    in-edges), the list of branching nodes with out-edges, and one step of the walk (the successor edge, or none where the
+    reference's walk stops) against the oracle's degree table and branching list.  64- and 128-bit keys, planted repeats."""
+    NONE = 0xFFFFFFFF
+    n_seg = 3
+    reads, seg_off, _ = synth.make_batch(n_seg, 5000, rl, 18, seed0=4400 + k, planted=True)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    b.build(k, genome_len_hint=5000)
+    seg = b.distinct()[0]
+    flags_all, next_all = b.graph()
+    for s in range(n_seg):
+        rs = _strs(reads[int(seg_off[s]):int(seg_off[s + 1])])
+        ref = orc.get_contigs(orc.kmers_from_reads(rs, k), k, 1, rows=1)
+        dk = b.distinct_kmers(s)[0]
+        a, e = int(seg[s]), int(seg[s + 1])
+        fl, nx = flags_all[a:e], next_all[a:e]
+        assert [d[:-1] for d in dk] == ref["edge_prefix"] and [d[1:] for d in dk] == ref["edge_suffix"]
+        deg = {n: (int(i), int(o)) for n, i, o in zip(ref["node"], ref["node_in"], ref["node_out"])}
+        branch = set(ref["branch"])
+        assert len(branch) > 2                                                # (the planted repeats branch)
+        first, out = {}, {}
+        for i, d in enumerate(dk):
+            first.setdefault(d[:-1], i)
+            out[d[:-1]] = out.get(d[:-1], 0) + 1
+        assert sorted({d[:-1] for d, f in zip(dk, fl) if f & 1}) == ref["branch"]
+        for i, d in enumerate(dk):
+            u, v = d[:-1], d[1:]
+            assert bool(fl[i] & 1) == (u in branch)                          # every out-edge of a branching node carries the flag
+            assert out[u] == deg[u][1]
+            if first[u] == i:
+                assert bool(fl[i] & 2) == (deg[u][0] >= 2), (s, u, deg[u])
+            if nx[i] == NONE:
+                assert v not in first or v in branch                         # the walk stops: no successor, or a branching node
+            else:
+                j = int(nx[i]) - a
+                assert 0 <= j < len(dk) and dk[j][:-1] == v and v not in branch and out[v] == 1 and deg[v][0] == 1
+    b.close()
+
+
 def test_non_acgt_is_rejected():
     with pytest.raises(ga.GasmError) as e:
         ga.get_contigs(["ACGTN"], 5, 1)
