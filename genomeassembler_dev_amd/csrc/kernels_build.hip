@@ -1124,60 +1124,71 @@ __global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_seg
     }
 }
 
+// k_rank_lds.  A first version decided "is my ancestor a head" from the ancestor's entry in every round (odd index, or an
+// entry that loops with distance 0, or loops with a distance: a folded cycle, or points at me ...) with a branch per case: 78
+// instructions per entry and round, 51 of them exec-mask bookkeeping — and with 16 waves on four SIMDs this kernel is bound
+// by instruction issue, not by its LDS operations (19 200 entries x 14 rounds: 2.5 LDS operations per clock): 0.097 ms on
+// cfg2.  So the list is first rewritten in LDS such that a round needs one test and no branch (17 instructions, 0.051 ms):
+//   * an entry whose ancestor is a head is TERMINAL — (0x8000 | its own ruler index) << 16, final from the start;
+//   * a dropped entry is DEAD — 0x8000FFFF (the terminal flag over index 0, with a distance no terminal entry has);
+//   * every other entry holds its ancestor's RULER INDEX (15 bits) and the distance to it.
+// A round: gather my ancestor's entry; bit 31 set -> I stop (my ancestor is a terminal ruler t and my distance to it is
+// known — or it is dead, which the end sorts out); else hop.  All of it is selects on integers; entries that have stopped
+// gather and rewrite themselves (LDS operations are not what the kernel is short of).  Members of isolated cycles never
+// stop and are dropped after max_rounds.  Which head t stands for, and t's distance to it, is t's original record in rtab:
+// one gather per ruler at the very end.
+#define GASM_RANK_DEAD 0x8000FFFFu
 __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __restrict__ rtab, u64* __restrict__ link, int max_rounds,
-                                                   u32 rshift, u32 lds_entries, u32* __restrict__ flags) {
+                                                    u32 rshift, u32 lds_entries, u32* __restrict__ flags) {
     const u32 rmask = (1u << rshift) - 1u;
-    extern __shared__ u32 s_e[];
+    extern __shared__ u32 s_e[];                       // lds_entries + 1 (the last one takes the writes of entries past the list)
     __shared__ u32 s_active;
     const u32 seg = blockIdx.x;
     const u32 nb = 1u << gv.bbits;
     const u32 lo = gv.dstart[seg * nb], hi = gv.dstart[(seg + 1) * nb];
     const u32 nr = (hi - lo + rmask) >> rshift;
-    // the launch sized the LDS list from an estimate: a segment that does not fit (or has more than 65534 edges, the
-    // range of the packed entries) is left alone and reported; the host then ranks with whole-GPU pointer doubling
     if (nr > lds_entries || hi - lo > 65534u) { if (threadIdx.x == 0) flags[1] = 1u; return; }
     const u32* src = rtab + (lo >> rshift) + seg;
-    // a thread owns entries threadIdx.x + 1024 q and keeps them in registers: a doubling step is then one LDS gather
-    // (the ancestor's entry) and one LDS write (so that others see the progress) — the kernel is bound by LDS operations
     u32 mine[32];
-    u32 done = 0;                                     // bit q: entry q of this thread is final (or dead)
+    u32 live = 0;                                     // bit q: entry q of this thread is still hopping
 #pragma unroll
     for (u32 q = 0; q < 32; ++q) {
         const u32 r = threadIdx.x + 1024 * q;
-        mine[q] = r < nr ? src[r] : GASM_RANK_NONE;
-        if (r < nr) s_e[r] = mine[q];
-        // dead, or the ancestor is an odd head: final from the start
-        if (mine[q] == GASM_RANK_NONE || ((mine[q] >> 16) & rmask)) done |= 1u << q;
+        u32 e = r < nr ? src[r] : GASM_RANK_NONE;
+        bool hopping = false;
+        if (e == GASM_RANK_NONE) e = GASM_RANK_DEAD;
+        else {
+            const u32 a = e >> 16;
+            if ((a & rmask) || (a == (r << rshift) && !(e & 0xFFFFu))) e = (0x8000u | r) << 16;       // my ancestor is a head (or I am one)
+            else if (a == (r << rshift)) e = GASM_RANK_DEAD;                                           // around a cycle, back at myself
+            else { e = ((a >> rshift) << 16) | (e & 0xFFFFu); hopping = true; }
+        }
+        mine[q] = e;
+        if (r < nr) s_e[r] = e;
+        live |= (u32)hopping << q;
     }
     for (int round = 0; round < max_rounds; ++round) {
         if (threadIdx.x == 0) s_active = 0;
         __syncthreads();
-        bool any = false;
+        u32 any = 0;
 #pragma unroll
         for (u32 q0 = 0; q0 < 32; q0 += 8) {
-            if (((done >> q0) & 0xFFu) == 0xFFu) continue;        // nothing open in this batch
-            u32 ea[8];
+            if (((live >> q0) & 0xFFu) == 0) continue;
+            u32 x[8];
 #pragma unroll
-            for (u32 u = 0; u < 8; ++u) ea[u] = ((done >> (q0 + u)) & 1u) ? 0u : s_e[mine[q0 + u] >> (16 + rshift)];
+            for (u32 u = 0; u < 8; ++u) x[u] = s_e[(mine[q0 + u] >> 16) & 0x7FFFu];
 #pragma unroll
             for (u32 u = 0; u < 8; ++u) {
                 const u32 q = q0 + u;
-                if ((done >> q) & 1u) continue;
-                const u32 r = threadIdx.x + 1024 * q, e = mine[q], a = e >> 16;
-                u32 ne;
-                if (ea[u] == GASM_RANK_NONE) { ne = GASM_RANK_NONE; done |= 1u << q; }
-                else if ((ea[u] >> 16) == a) {                                            // the ancestor is an even head ...
-                    done |= 1u << q;
-                    if (!(ea[u] & 0xFFFFu)) continue;
-                    ne = GASM_RANK_NONE;                                                  // ... or a cycle folded onto itself
-                } else if ((ea[u] >> 16) == (r << rshift)) { ne = GASM_RANK_NONE; done |= 1u << q; }   // my own cycle
-                else {
-                    ne = (ea[u] & 0xFFFF0000u) | (((e & 0xFFFFu) + (ea[u] & 0xFFFFu)) & 0xFFFFu);
-                    if ((ne >> 16) & rmask) done |= 1u << q;                   // reached a head that is no ruler
-                    else any = true;
-                }
+                const u32 r = threadIdx.x + 1024 * q, e = mine[q];
+                const u32 lv = (live >> q) & 1u, stop = x[u] >> 31;
+                const u32 hop = lv & ~stop;
+                const u32 hopped = (x[u] & 0xFFFF0000u) | ((e + x[u]) & 0xFFFFu);
+                const u32 ne = hop ? hopped : e;
+                live &= ~((lv & stop) << q);
+                any |= hop;
                 mine[q] = ne;
-                s_e[r] = ne;
+                s_e[min(r, nr)] = ne;
             }
         }
         if (any) s_active = 1;
@@ -1186,14 +1197,22 @@ __global__ void __launch_bounds__(1024) k_rank_lds(GraphView gv, const u32* __re
         __syncthreads();
         if (!go) break;
     }
-    // final links of the rulers; what is still open after 2^18 steps' worth of doubling sits on an isolated cycle
+    // final links: a stopped ruler through its terminal ruler's record (a terminal one through its own); what is still
+    // hopping after 2^max_rounds steps' worth of doubling sits on an isolated cycle; behind a dropped ruler: dropped
 #pragma unroll
     for (u32 q = 0; q < 32; ++q) {
         const u32 r = threadIdx.x + 1024 * q;
         if (r >= nr) continue;
         const u32 e = mine[q];
-        const bool fin = (done >> q) & 1u;
-        link[lo + (r << rshift)] = (fin && e != GASM_RANK_NONE) ? (((u64)(lo + (e >> 16)) << 32) | GASM_LINK_DONE | (e & 0xFFFFu)) : ~0ull;
+        u64 l = ~0ull;
+        if (!((live >> q) & 1u) && e != GASM_RANK_DEAD) {
+            const u32 t = (e >> 16) & 0x7FFFu;                       // the terminal ruler (myself for a terminal entry)
+            if (s_e[t] != GASM_RANK_DEAD) {
+                const u32 ot = src[t];
+                l = ((u64)(lo + (ot >> 16)) << 32) | GASM_LINK_DONE | (((e & 0xFFFFu) + (ot & 0xFFFFu)) & 0xFFFFu);
+            }
+        }
+        link[lo + (r << rshift)] = l;
     }
 }
 

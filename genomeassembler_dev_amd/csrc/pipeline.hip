@@ -662,7 +662,7 @@ static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
         u32 lds_entries = 32767;
         if (S > (u32)ctx->n_cu) lds_entries = std::min<u32>(32767, (((est + est / 4) >> rshift) + 1024) & ~1023u);
         GLAUNCH(ctx, "k_rank_rulers", k_rank_rulers, seg_grid(rchunks, S), dim3(GASM_WG), 0, gv, S, rchunks, bs.d_link.as<u64>(), bs.d_rtab.as<u32>(), rshift, d_fl);
-        GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)lds_entries * 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), knobs().rank_rounds, rshift,
+        GLAUNCH(ctx, "k_rank_lds", k_rank_lds, dim3(S), dim3(1024), (size_t)lds_entries * 4 + 4, gv, bs.d_rtab.as<u32>(), bs.d_link.as<u64>(), knobs().rank_rounds, rshift,
                 lds_entries, d_fl);
         // the odd edges: the ruler behind an edge is usually one or two steps away (a longer gap is geometrically rare)
         // (a thread stops as soon as its link is final; spans grow by a factor of jumps + 1 per launch at the very

@@ -112,7 +112,12 @@ def test_graph_degrees_and_branching_nodes_against_oracle(k, rl):
     reference's walk stops) against the oracle's degree table and branching list.  64- and 128-bit keys, planted repeats."""
     NONE = 0xFFFFFFFF
     n_seg = 3
-    reads, seg_off, _ = synth.make_batch(n_seg, 5000, rl, 18, seed0=4400 + k, planted=True)
+    parts, off = [], [0]
+    for s in range(n_seg):      # repeats short enough to fit a 6 kb segment: branching nodes, and chains between them
+        g = synth.make_segment(4400 + k + s, 6000, n_short=6, short_len=120, n_long=2, long_len=500, tandem_len=200, planted=True)
+        parts.append(synth.simulate_reads(g, rl, 18, 77 + s))
+        off.append(off[-1] + parts[-1].shape[0])
+    reads, seg_off = np.concatenate(parts, axis=0), np.array(off, dtype=np.uint64)
     b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
     b.build(k, genome_len_hint=5000)
     seg = b.distinct()[0]
