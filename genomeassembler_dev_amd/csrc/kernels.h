@@ -46,13 +46,19 @@ __device__ __forceinline__ u32 graph_lower_bound(const GraphView& gv, u32 seg, c
     const u32 nb = 1u << gv.bbits;
     const int low = 2 * gv.k - gv.bbits;
     const u32 gb = seg * nb + (gv.bbits ? kfield(t, low) : 0u);
-    const u32 base = gv.dstart[gb];
-    *bucket_hi = gv.dstart[gb + 1];
+    // (two neighbours of a directory = ONE load each, unaligned: the lookups of the graph kernels are bound by the number of
+    // line requests they send to L2 — ~16 per clock and XCD —, and a pair of 2- or 4-byte loads are two requests)
+    uint2 dd;
+    __builtin_memcpy(&dd, gv.dstart + gb, 8);
+    const u32 base = dd.x;
+    *bucket_hi = dd.y;
     const int bshift = low > gv.fbits ? low - gv.fbits : 0;
     const u32 nbin = 1u << gv.fbits;
     const u16* f = gv.fdir + (u64)gb * (nbin + 1) + (kfield(t, bshift) & (nbin - 1));
-    u32 lo = base + f[0];
-    u32 hi = base + f[1];
+    u32 ff;
+    __builtin_memcpy(&ff, f, 4);
+    u32 lo = base + (ff & 0xFFFFu);
+    u32 hi = base + (ff >> 16);
     // (a directory that is not one — a bucket of a failed build attempt whose kernels were queued ahead of its report —
     // must still end the search: bounds inside the bucket, in order)
     if (hi > *bucket_hi) hi = *bucket_hi;

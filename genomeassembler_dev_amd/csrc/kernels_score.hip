@@ -64,20 +64,32 @@ __global__ void __launch_bounds__(GASM_WG) k_read_insert(ReadSet rs, SeedTable s
     }
 }
 
-// `len` bases of two packed streams equal?  128 bases per round: five words from either stream (independent loads; both
-// streams end in four padding words), aligned in registers.
+// `len` bases of two packed streams equal?  160 bases per round: up to six words from either stream as three 16-byte loads
+// (independent; a 150-base read is one round of six requests — word by word and 128 bases per round it was twenty, and the
+// scorer is bound by the requests it sends), aligned in registers.  Both streams end in four padding words; the third pair
+// is only touched when more than 96 bases remain, i.e. when the fourth word still holds bases.
+typedef unsigned long long gasm_u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gasm_u64x2 load_pair(const u64* __restrict__ p) {
+    gasm_u64x2 v;
+    __builtin_memcpy(&v, p, 16);                  // (8-byte aligned: one global_load_dwordx4)
+    return v;
+}
 __device__ __forceinline__ bool bases_equal(const u64* __restrict__ aw, u64 a0, const u64* __restrict__ bw, u64 b0, u32 len) {
     bool same = true;
-    for (u32 o = 0; o < len && same; o += 128) {
+    for (u32 o = 0; o < len && same; o += 160) {
         const u64 ra = (a0 + o) >> 5, ca = (b0 + o) >> 5;
         const u32 sr = (u32)((a0 + o) & 31) << 1, sc = (u32)((b0 + o) & 31) << 1;
-        u64 rw[5], cw[5];
+        const u32 nb = len - o;
+        u64 rw[6], cw[6];
+        const gasm_u64x2 r0 = load_pair(aw + ra), r1 = load_pair(aw + ra + 2), c0 = load_pair(bw + ca), c1 = load_pair(bw + ca + 2);
+        gasm_u64x2 r2 = {0, 0}, c2 = {0, 0};
+        if (nb > 96) { r2 = load_pair(aw + ra + 4); c2 = load_pair(bw + ca + 4); }
+        rw[0] = r0.x; rw[1] = r0.y; rw[2] = r1.x; rw[3] = r1.y; rw[4] = r2.x; rw[5] = r2.y;
+        cw[0] = c0.x; cw[1] = c0.y; cw[2] = c1.x; cw[3] = c1.y; cw[4] = c2.x; cw[5] = c2.y;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { rw[i] = aw[ra + i]; cw[i] = bw[ca + i]; }
-#pragma unroll
-        for (u32 j = 0; j < 4; ++j) {
-            if (o + 32 * j >= len) break;
-            const u32 left = len - o - 32 * j, nbase = left < 32 ? left : 32;
+        for (u32 j = 0; j < 5; ++j) {
+            if (32 * j >= nb) break;
+            const u32 left = nb - 32 * j, nbase = left < 32 ? left : 32;
             const u64 x = funnel64(rw[j], rw[j + 1], sr), y = funnel64(cw[j], cw[j + 1], sc);
             same = same && ((x ^ y) >> (64 - 2 * nbase)) == 0;
         }
@@ -139,7 +151,7 @@ __global__ void __launch_bounds__(GASM_WG) k_first_to_poscnt(const u32* __restri
 // Returns the global base position of the hit, or ~0 when the read matches no contig.
 template <class K>
 __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& gv, const u64* __restrict__ link,
-                                           const u32* __restrict__ e_cid, const PathSet& ps, u32 seg, u64 r, u32* path) {
+                                           const u32* __restrict__ e_cid, const PathSet& ps, u32 seg, u64 r, u32* path, u64* pbeg, u64* pend) {
     u64 p0; u32 len;
     read_span(rs, r, &p0, &len);
     if (len < (u32)gv.k) return ~0ull;
@@ -152,8 +164,10 @@ __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& g
     if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return ~0ull;   // on an isolated cycle: part of no contig
     const u32 c = e_cid[a];
     *path = c;
-    const u64 g = ps.p_off[c] + ((u32)l & 0x7FFFFFFFu);
-    if (g + len > ps.p_off[c + 1]) return ~0ull;
+    const gasm_u64x2 po = load_pair(ps.p_off + c);              // the contig's first base and its end
+    *pbeg = po.x; *pend = po.y;
+    const u64 g = po.x + ((u32)l & 0x7FFFFFFFu);
+    if (g + len > po.y) return ~0ull;
     // (128 bases per round, aligned in registers: word-by-word with an early exit was a chain of dependent round trips)
     const bool same = bases_equal(rs.words, p0, ps.words, g, len);
     return same ? g : ~0ull;
@@ -187,10 +201,10 @@ __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, Graph
     __syncthreads();
     for (u64 r = r0 + threadIdx.x; r < r1; r += GASM_WG) {
         u32 c = 0;
-        const u64 g = graph_match<K>(rs, gv, link, e_cid, ps, seg, r, &c);
+        u64 pb = 0, pe = 0;
+        const u64 g = graph_match<K>(rs, gv, link, e_cid, ps, seg, r, &c, &pb, &pe);
         if (g == ~0ull) continue;
-        const u64 pb = ps.p_off[c];
-        const u32 plen = (u32)(ps.p_off[c + 1] - pb);
+        const u32 plen = (u32)(pe - pb);
         u32 idx;
         long long fx = 0;
         if (break_window(ps.words, pb, plen, (u32)(g - pb), kmer, &idx)) fx = dfix[idx];
