@@ -104,6 +104,24 @@ __device__ __forceinline__ void for_seg_edges(const u32* __restrict__ dstart, u3
     }
 }
 
+// The same, GASM_EDGE_ILP edges per thread and round handed over together: these kernels are one or two dependent gathers
+// per edge and live on loads in flight — with one edge per thread the 2048 threads of a CU are all the parallelism there is.
+// f(seg, lo, hi, i[ILP], ok[ILP]); launch with chunks = ceil(edges / (GASM_WG * GASM_EDGE_ILP)).
+#define GASM_EDGE_ILP 4
+template <class F>
+__device__ __forceinline__ void for_seg_edge_groups(const u32* __restrict__ dstart, u32 nb, u32 n_segments, u32 chunks, F&& f) {
+    u32 seg, chunk;
+    if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;
+    const u32 lo = dstart[seg * nb], hi = dstart[(seg + 1) * nb];
+    for (u32 base = chunk * (GASM_WG * GASM_EDGE_ILP); base < hi - lo; base += chunks * (GASM_WG * GASM_EDGE_ILP)) {
+        u32 i[GASM_EDGE_ILP];
+        bool ok[GASM_EDGE_ILP];
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q) { i[q] = lo + base + q * GASM_WG + threadIdx.x; ok[q] = i[q] < hi; }
+        f(seg, lo, hi, i, ok);
+    }
+}
+
 template <class T>
 __device__ __forceinline__ u32 lower_bound_dev(const T* __restrict__ a, u32 lo, u32 hi, T t) {
     while (lo < hi) {

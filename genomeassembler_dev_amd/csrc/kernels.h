@@ -124,7 +124,7 @@ __global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u3
 __global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* seg_cstart, const u64* seg_bstart, u32* e_cid, u64* e_coff,
                                u64* c_off, u32 n_segments, u32 chunks);
 template <class K>
-__global__ void k_contig_emit(GraphView gv, const u64* link, const u64* e_coff, u8* out, u32 n_segments, u32 chunks);
+__global__ void k_contig_emit(GraphView gv, const u64* link, const u32* nxt, const u64* e_coff, u8* out, u32 n_segments, u32 chunks);
 
 // ---- kernels_pool.hip
 template <class K>

@@ -983,9 +983,15 @@ template __global__ void k_edge_target<K128>(GraphView, u32, u32, u32*, u32*);
 
 __global__ void __launch_bounds__(GASM_WG) k_edge_multi(GraphView gv, u32 n_segments, u32 chunks, const u32* __restrict__ tgt,
                                                         const u32* __restrict__ claim, u8* __restrict__ eflag) {
-    for_seg_edges(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32, u32, u32 i) {
-        const u32 j = tgt[i];
-        if (j != GASM_NONE32 && claim[j] != i) eflag[j] = 2;
+    for_seg_edge_groups(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32, u32, const u32 (&i)[GASM_EDGE_ILP], const bool (&ok)[GASM_EDGE_ILP]) {
+        u32 j[GASM_EDGE_ILP], c[GASM_EDGE_ILP];
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q) j[q] = ok[q] ? tgt[i[q]] : GASM_NONE32;
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q) c[q] = j[q] != GASM_NONE32 ? claim[j[q]] : 0u;
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q)
+            if (j[q] != GASM_NONE32 && c[q] != i[q]) eflag[j[q]] = 2;
     });
 }
 
@@ -1016,13 +1022,21 @@ template __global__ void k_node_flags<K128>(GraphView, u32, u32, const u32*, u8*
 // (nxt may be the array claim lived in: claim is dead by now.)
 __global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u32* __restrict__ tgt,
                                                        const u8* __restrict__ eflag, u32* __restrict__ nxt, u64* __restrict__ link) {
-    for_seg_edges(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32, u32, u32 i) {
-        const u32 j = tgt[i];
-        const u32 n = (j != GASM_NONE32 && !(eflag[j] & 1)) ? j : GASM_NONE32;   // the target has out-edges and is not branching
-        nxt[i] = n;
-        const u64 me_head = (eflag[i] & 1) ? GASM_LINK_DONE : 0ull;
-        if (n != GASM_NONE32) link[n] = ((u64)i << 32) | me_head | 1ull;
-        if (me_head) link[i] = ((u64)i << 32) | GASM_LINK_DONE;
+    for_seg_edge_groups(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32, u32, const u32 (&i)[GASM_EDGE_ILP], const bool (&ok)[GASM_EDGE_ILP]) {
+        u32 j[GASM_EDGE_ILP], efi[GASM_EDGE_ILP], efj[GASM_EDGE_ILP];
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q) { j[q] = ok[q] ? tgt[i[q]] : GASM_NONE32; efi[q] = ok[q] ? (u32)eflag[i[q]] : 0u; }
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q) efj[q] = j[q] != GASM_NONE32 ? (u32)eflag[j[q]] : 1u;
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q) {
+            if (!ok[q]) continue;
+            const u32 n = (j[q] != GASM_NONE32 && !(efj[q] & 1)) ? j[q] : GASM_NONE32;   // the target has out-edges and is not branching
+            nxt[i[q]] = n;
+            const u64 me_head = (efi[q] & 1) ? GASM_LINK_DONE : 0ull;
+            if (n != GASM_NONE32) link[n] = ((u64)i[q] << 32) | me_head | 1ull;
+            if (me_head) link[i[q]] = ((u64)i[q] << 32) | GASM_LINK_DONE;
+        }
     });
 }
 
@@ -1310,24 +1324,54 @@ __global__ void __launch_bounds__(GASM_WG) k_contig_place(GraphView gv, const u8
     });
 }
 
-// Every edge on a chain writes its last base at head offset + (k-1) + distance; the head also writes its node.
+// Contig text.  The edge at distance d from its chain's head ends at base (k-1) + d of the contig, and its key holds the
+// k bases before that: so only every eighth edge of a chain (d % 8 == 0) and the last one write — the eight bases that end
+// with their own, as ONE 8-byte store — and the head adds the rest of its node.  (One byte per edge was 3.8 M scattered store
+// requests and as many gathers of the head's offset; the graph kernels are bound by the number of requests they send.)
+__device__ __forceinline__ u32 klow16(u64 a) { return (u32)a & 0xFFFFu; }
+__device__ __forceinline__ u32 klow16(const K128& a) { return (u32)a.lo & 0xFFFFu; }
 template <class K>
-__global__ void __launch_bounds__(GASM_WG) k_contig_emit(GraphView gv, const u64* __restrict__ link,
+__global__ void __launch_bounds__(GASM_WG) k_contig_emit(GraphView gv, const u64* __restrict__ link, const u32* __restrict__ nxt,
                                                          const u64* __restrict__ e_coff, u8* __restrict__ out, u32 n_segments,
                                                          u32 chunks) {
-    // (segment-major: the byte scatter into a segment's contigs merges in one L2)
-    for_seg_edges(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32, u32, u32 i) {
-        const u64 l = link[i];
-        const u32 a = (u32)(l >> 32);
-        if (a == GASM_NONE32 || !(l & GASM_LINK_DONE)) return;
-        const K key = reinterpret_cast<const K*>(gv.dk_key)[i];
-        const u64 off = e_coff[a];
+    // (segment-major: the stores into a segment's contigs merge in one L2)
+    for_seg_edge_groups(gv.dstart, 1u << gv.bbits, n_segments, chunks, [&](u32, u32, u32, const u32 (&i)[GASM_EDGE_ILP], const bool (&ok)[GASM_EDGE_ILP]) {
+        u64 l[GASM_EDGE_ILP], off[GASM_EDGE_ILP];
+        u32 nx[GASM_EDGE_ILP];
+        K key[GASM_EDGE_ILP];
+        bool on[GASM_EDGE_ILP];
         const int k = gv.k;
-        out[off + (k - 1) + ((u32)l & 0x7FFFFFFFu)] = "ACGT"[klow2(key)];
-        if (a == i) {
-            for (int j = 0; j < k - 1; ++j) out[off + j] = "ACGT"[klow2(kshr(key, 2 * (k - 1 - j)))];
+        const bool wide = k >= 8;            // (a key of fewer than eight bases: every edge writes its own last base)
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q) {
+            l[q] = ok[q] ? link[i[q]] : ~0ull;
+            nx[q] = ok[q] ? nxt[i[q]] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q) {
+            const u32 a = (u32)(l[q] >> 32), d = (u32)l[q] & 0x7FFFFFFFu;
+            on[q] = a != GASM_NONE32 && (l[q] & GASM_LINK_DONE) && (!wide || !(d & 7u) || nx[q] == GASM_NONE32);
+            off[q] = on[q] ? e_coff[a] : 0ull;
+            key[q] = reinterpret_cast<const K*>(gv.dk_key)[on[q] ? i[q] : 0u];
+        }
+#pragma unroll
+        for (int q = 0; q < GASM_EDGE_ILP; ++q) {
+            if (!on[q]) continue;
+            const u32 d = (u32)l[q] & 0x7FFFFFFFu, low = klow16(key[q]);
+            const u64 last = off[q] + (u32)(k - 1) + d;                 // where my own last base goes
+            if (wide) {
+                u64 txt = 0;
+#pragma unroll
+                for (u32 t = 0; t < 8; ++t) txt |= (u64)((0x54474341u >> (8u * ((low >> (2u * (7u - t))) & 3u))) & 0xFFu) << (8u * t);   // "ACGT"
+                __builtin_memcpy(out + last - 7, &txt, 8);
+            } else {
+                out[last] = "ACGT"[low & 3u];
+            }
+            if ((u32)(l[q] >> 32) == i[q]) {                           // the head: the bases of its node the store above does not reach
+                for (int j = 0; j < (wide ? k - 8 : k - 1); ++j) out[off[q] + j] = "ACGT"[klow2(kshr(key[q], 2 * (k - 1 - j)))];
+            }
         }
     });
 }
-template __global__ void k_contig_emit<u64>(GraphView, const u64*, const u64*, u8*, u32, u32);
-template __global__ void k_contig_emit<K128>(GraphView, const u64*, const u64*, u8*, u32, u32);
+template __global__ void k_contig_emit<u64>(GraphView, const u64*, const u32*, const u64*, u8*, u32, u32);
+template __global__ void k_contig_emit<K128>(GraphView, const u64*, const u32*, const u64*, u8*, u32, u32);

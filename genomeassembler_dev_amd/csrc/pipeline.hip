@@ -641,14 +641,16 @@ static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
     const u32 est = std::max<u32>(1, (u32)std::min<u64>(bs.maxD_est, bs.maxD_cap));   // grids: the kernels loop when a segment is larger
     const u32 dchunks = (u32)ceil_div_u64(est, GASM_WG);     // workgroups per segment of the per-edge kernels
     const dim3 grid_seg = seg_grid(dchunks, S);
+    const u32 gchunks = (u32)ceil_div_u64(est, GASM_WG * GASM_EDGE_ILP);     // the kernels that take GASM_EDGE_ILP edges per thread and round
+    const dim3 grid_grp = seg_grid(gchunks, S);
     u32* const d_tgt = bs.d_ecid.as<u32>();        // first out-edge of every edge's target node; e_cid is written later (k_contig_scan)
     if (W == 1) GLAUNCH(ctx, "k_edge_target", k_edge_target<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim);
     else GLAUNCH(ctx, "k_edge_target", k_edge_target<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim);
-    GLAUNCH(ctx, "k_edge_multi", k_edge_multi, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim, bs.d_eflag.as<u8>());
+    GLAUNCH(ctx, "k_edge_multi", k_edge_multi, grid_grp, dim3(GASM_WG), 0, gv, S, gchunks, d_tgt, d_claim, bs.d_eflag.as<u8>());
     // (k_node_flags also initialises link = none and clen = 0 for its edge)
     if (W == 1) GLAUNCH(ctx, "k_node_flags", k_node_flags<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_claim, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
     else GLAUNCH(ctx, "k_node_flags", k_node_flags<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_claim, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
-    GLAUNCH(ctx, "k_edge_next", k_edge_next, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
+    GLAUNCH(ctx, "k_edge_next", k_edge_next, grid_grp, dim3(GASM_WG), 0, gv, S, gchunks, d_tgt, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
     u32* const act = d_fl + 16;     // "still active" words of the k_link_jump launches
     const u32 jchunks = (u32)ceil_div_u64(est, GASM_WG * 4);      // GASM_JUMP_ILP links per thread
     bs.ranked_in_lds = est <= 65534 && !bs.rank_global && !knobs().rank_global;
@@ -701,11 +703,11 @@ static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
     GLAUNCH(ctx, "k_contig_place", k_contig_place, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(),
             bs.d_seg_cstart.as<u32>(), bs.d_seg_bstart.as<u64>(), bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_c_off.as<u64>(), S, dchunks);
     if (W == 1) {
-        GLAUNCH(ctx, "k_contig_emit", k_contig_emit<u64>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_link.as<u64>(),
-                bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, dchunks);
+        GLAUNCH(ctx, "k_contig_emit", k_contig_emit<u64>, grid_grp, dim3(GASM_WG), 0, gv, bs.d_link.as<u64>(), bs.d_nxt.as<u32>(),
+                bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, gchunks);
     } else {
-        GLAUNCH(ctx, "k_contig_emit", k_contig_emit<K128>, grid_seg, dim3(GASM_WG), 0, gv, bs.d_link.as<u64>(),
-                bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, dchunks);
+        GLAUNCH(ctx, "k_contig_emit", k_contig_emit<K128>, grid_grp, dim3(GASM_WG), 0, gv, bs.d_link.as<u64>(), bs.d_nxt.as<u32>(),
+                bs.d_ecoff.as<u64>(), bs.d_contig_ascii.as<u8>(), S, gchunks);
     }
     bs.pending = true;
     return GASM_OK;
