@@ -13,6 +13,7 @@ typedef uint8_t u8;
 #define GASM_EMPTY64 0xFFFFFFFFFFFFFFFFull
 #define GASM_NONE32 0xFFFFFFFFu
 #define GASM_LINK_DONE 0x80000000ull   // link word: ancestor << 32 | done << 31 | distance
+#define GASM_LINK_TAG 0x40000000ull    // (between k_rank_rulers and k_link_jump only) ancestor = a ruler BEHIND this edge, distance = how far behind
 
 // ----------------------------------------------------------------------------------------------------------------
 // Packed base streams.  Base j of a stream lives in 64-bit word j>>5 at bit 62-2*(j&31) (first base most

@@ -1077,6 +1077,13 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
             for (int q = 0; q < GASM_JUMP_ILP; ++q) {
                 if (!act[q]) continue;
                 if ((u32)(la[q] >> 32) == GASM_NONE32) { l[q] = ~0ull; act[q] = false; continue; }   // behind a dropped edge: dropped too
+                if (l[q] & GASM_LINK_TAG) {
+                    // tagged by k_rank_rulers: `distance` edges ahead of the ruler whose final link this is — same head, that much nearer
+                    if (!(la[q] & GASM_LINK_DONE)) { l[q] = ~0ull; act[q] = false; continue; }        // (a ruler is final or dropped by now)
+                    l[q] = (la[q] & (0xFFFFFFFF00000000ull | GASM_LINK_DONE)) | (u64)((((u32)la[q] & 0x7FFFFFFFu) - ((u32)l[q] & 0x3FFFFFFFu)) & 0x3FFFFFFFu);
+                    act[q] = false;
+                    continue;
+                }
                 l[q] = (la[q] & (0xFFFFFFFF00000000ull | GASM_LINK_DONE)) | (u64)(((u32)l[q] + (u32)la[q]) & 0x7FFFFFFFu);
                 if (l[q] & GASM_LINK_DONE) act[q] = false;
             }
@@ -1109,7 +1116,7 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
 // rulers = edges whose local index is a multiple of 1 << rshift (a launch parameter: 1 for batches of many segments —
 // every CU has its own segment, LDS time per segment is what counts — 2 for a few segments, where the LDS kernel's
 // rounds are the longest latency of the whole build and the longer walks of the other two kernels are spread over the chip)
-__global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, const u64* __restrict__ link,
+__global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, u64* __restrict__ link,
                                                          u32* __restrict__ rtab, u32 rshift, u32* __restrict__ flags) {
     const u32 rmask = (1u << rshift) - 1u;
     u32 seg, chunk;
@@ -1123,6 +1130,10 @@ __global__ void __launch_bounds__(GASM_WG) k_rank_rulers(GraphView gv, u32 n_seg
         int step = 0;
         for (; step < 4096; ++step) {                     // the walk ends at the first ruler: 2^rshift steps on average
             const u64 l = link[cur];
+            // an edge the walk passes (no ruler: only this walk ever reads its link) learns where it is: `acc` edges ahead of
+            // ruler i.  k_link_jump then finishes it with ONE gather of the ruler's final link, instead of following
+            // its predecessors one by one (runs of non-rulers are geometric: the longest of a wave's 256 is ~9 steps)
+            if (cur != i) link[cur] = ((u64)i << 32) | GASM_LINK_TAG | acc;
             const u32 a = (u32)(l >> 32);
             if (a == GASM_NONE32) break;
             acc += (u32)l & 0x7FFFFFFFu;
