@@ -80,6 +80,25 @@ __device__ __forceinline__ u32 block_excl_scan(u32 v, u32* s_tmp, u32* total) {
     return base + inc - v;
 }
 
+// The same without the trailing barrier: for callers whose next write to s_tmp lies behind another barrier anyway.
+template <int NT>
+__device__ __forceinline__ u32 block_excl_scan_open(u32 v, u32* s_tmp, u32* total) {
+    constexpr int NW = NT / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 inc = wave_incl_scan(v);
+    if (lane == 63) s_tmp[wv] = inc;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        const u32 t = s_tmp[i];
+        if (i < wv) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
 // Segment-major grids, XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2 (observed
 // behaviour, a speed assumption only), so the C workgroups of a segment get linear ids that are congruent mod 8:
 // everything the segment's kernels gather from — its slice of the sorted k-mers, its links, its contigs — then lives

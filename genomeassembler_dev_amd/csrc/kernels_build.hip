@@ -495,7 +495,7 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 4) k_bucket_partition(ReadSet rs
         }
         const u32 cnt = c0 + c1 + c2 + c3, padc = (cnt + padm) & ~padm;
         u32 total;
-        const u32 soff = block_excl_scan<GASM_TILE_WG>(padc, s_tmp, &total);
+        const u32 soff = block_excl_scan_open<GASM_TILE_WG>(padc, s_tmp, &total);      // (s_tmp is next written two barriers on)
         u32 run = 0;
         u64 beg = 0, end = 0;                      // the region of bucket `tid` (a few KB of directory per segment: L2 hits, used after the staging)
         if (t < nb) {
@@ -553,7 +553,8 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 4) k_bucket_partition(ReadSet rs
             }
         }
         if (++tile >= tile_end) break;
-        __syncthreads();          // staging is free again
+        // (no barrier here: the next tile's first writes to the staging area, the bases and the run offsets all lie behind its
+        // first barrier, which a thread reaches only after its own reads of this flush; its counting touches the counters only)
         ti = tin;
         rl.template wait_all_but<NFL>();
     }
