@@ -431,7 +431,7 @@ template __global__ void k_bucket_scatter<K128>(ReadSet, const uint4*, int, int,
 // de-duplication leaves such a bucket empty, and pipeline_build_finish repeats the build with the two-pass kernels.
 // Memory operations of a wave: [next tile's words, region bounds] [cursor atomic: wave(s) of the bucket threads]
 // [NFL stores]; the atomic's value is used before the flush, so the wait at the top stays "all but the NFL stores".
-// LDS: staging as above + nb * 40 + 80 bytes: two workgroups per CU up to 256 buckets.
+// LDS: staging as above + nb * 44 + 80 bytes: two workgroups per CU up to 128 buckets.
 // ================================================================================================================
 template <class K>
 __global__ void __launch_bounds__(GASM_TILE_WG, 4) k_bucket_partition(ReadSet rs, const uint4* __restrict__ tinfo, int k, int bbits, u32 g, u32 padm,
@@ -449,6 +449,7 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 4) k_bucket_partition(ReadSet rs
     u32* s_base = reinterpret_cast<u32*>(s_comb + ((nb + 1) & ~1u));         // 4 per bucket: staging index of rank 0 of every sub-counter
     u32* s_cnt = s_base + 4 * nb + 4;                                        // 4 per bucket (sub-counters) + dummy bin; 16-byte aligned
     u32* s_tmp = s_cnt + 4 * nb + 4;                                         // 12
+    u32* s_fill = s_tmp + 12;                                                // nb: where a bucket's fillers start << 4 | how many
     const int bshift = 2 * k - bbits;
 
     const u32 per_wg = (n_tiles + gridDim.x - 1) / gridDim.x;
@@ -504,9 +505,15 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 4) k_bucket_partition(ReadSet rs
             beg = bstart[gb]; end = bstart[gb + 1];
             *reinterpret_cast<uint4*>(&s_base[4 * t]) = make_uint4(soff, soff + c0, soff + c0 + c1, soff + c0 + c1 + c2);
             *reinterpret_cast<uint4*>(&s_cnt[4 * t]) = make_uint4(zero, zero, zero, zero);
-            for (u32 i = cnt; i < padc; ++i) s_key[soff + i] = key_filler<K>(t, bshift);
+            s_fill[t] = ((soff + cnt) << 4) | (padc - cnt);
         }
         __syncthreads();
+        // ---- fillers of the padded runs: eight threads per bucket (one wave writing up to 15 fillers for each of its buckets
+        // one after the other kept the other seven waiting at the barrier above)
+        for (u32 x = t; x < 8 * nb; x += GASM_TILE_WG) {
+            const u32 b = x >> 3, v = s_fill[b];
+            for (u32 f = x & 7u; f < (v & 15u); f += 8) s_key[(v >> 4) + f] = key_filler<K>(b, bshift);
+        }
         // ---- stage
         {
             // (in place: the rank becomes the staging index; the bucket is taken from the window again — keeping the 16 slots

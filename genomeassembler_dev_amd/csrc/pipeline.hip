@@ -497,7 +497,7 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
         HIPCHK(hipMemsetAsync(bs.d_flags.p, 0, 256 + (size_t)nbt * 4, ctx->stream));
         u32* const d_cursor = bs.d_flags.as<u32>() + 64;
         d_blen = d_cursor;
-        const size_t lds = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (GASM_TILE_WG / 8) * KB + (size_t)((nb + 1) & ~1u) * 8 + (size_t)(4 * nb + 4) * 8 + 48;
+        const size_t lds = (size_t)(W == 1 ? 18 : 9) * GASM_TILE_WG * KB + (GASM_TILE_WG / 8) * KB + (size_t)((nb + 1) & ~1u) * 8 + (size_t)(4 * nb + 4) * 8 + 48 + (size_t)nb * 4;
         const u32 grid_part = std::min<u32>(rd.n_tiles, (u32)ctx->n_cu * (u32)knobs().scatter_wgs);
         if (W == 1) {
             GLAUNCH(ctx, "k_bucket_partition", k_bucket_partition<u64>, dim3(grid_part), dim3(GASM_TILE_WG), lds, rs, rs.tile_info, k, bbits, g, padm, rd.n_tiles,
