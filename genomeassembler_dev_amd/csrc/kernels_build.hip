@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(64) k_seg_offsets(const u32* __restrict__ seg_
 // Memory operations of a wave retire in order (one counter, vmcnt, for loads and stores).  A load issued after the
 // flush would therefore wait for all of the flush's stores.  So the next tile's inputs (bucket counts, bases, read
 // words) are requested BEFORE the flush, and the flush issues exactly NFL stores per thread whatever the tile holds
-// (lanes past the end write to a per-wave scratch line): the wait at the top of the next tile is then "all but the
+// (lanes past the end write to a per-wave scratch slot): the wait at the top of the next tile is then "all but the
 // last NFL operations", written out explicitly.
 // LDS: NFL * 512 x 16 bytes (72 KB) + 64 trash slots + nb * 24 + 96 -> two workgroups per CU, for both key widths.
 // ================================================================================================================
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
     const u32 tile_end = min(n_tiles, (blockIdx.x + 1) * per_wg);
     u32 tile = blockIdx.x * per_wg;
     if (tile >= tile_end) return;
-    const u64 my_scratch = scratch + (u64)(((blockIdx.x & 1023u) * (GASM_TILE_WG / 64) + wv) * 64 + ln) * KPU;
+    const u64 my_scratch = scratch + (u64)((blockIdx.x & 1023u) * (GASM_TILE_WG / 64) + wv) * KPU;     // one 16-byte slot per wave (see k_bucket_partition)
 
     auto fetch = [&](u32 t, const TileInfo& ti, TilePrefetch<K>& pf) {
         pf.c01 = 0; pf.c23 = 0; pf.toff = 0; pf.bs_lo = 0; pf.bs_hi = 0;
@@ -535,7 +535,9 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 4) k_bucket_partition(ReadSet rs
             if (!fits) atomicOr(flags, 2u);
         }
         __syncthreads();
-        const u64 my_scratch = scratch + (u64)(((blockIdx.x & 1023u) * (GASM_TILE_WG / 64)) * 64 + t) * KPU;   // (wave * 64 + lane = t)
+        // (one 16-byte slot per wave, shared by its lanes past the end: 128 KB in all, resident in L2 — a slot per lane was an
+        // 8 MB region that kept being written back: 0.2 GB of the kernel's 1.9 GB of HBM writes)
+        const u64 my_scratch = scratch + (u64)((blockIdx.x & 1023u) * (GASM_TILE_WG / 64) + (t >> 6)) * KPU;
         // ---- stream out (as k_bucket_scatter; a run without room goes to the scratch line)
         static_assert(NFL % 3 == 0, "flush passes come in threes");
 #pragma unroll
