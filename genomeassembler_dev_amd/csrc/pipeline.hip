@@ -387,6 +387,7 @@ void BuildState::release() {
                     &d_eflag, &d_nxt, &d_link, &d_clen, &d_ecid, &d_ecoff, &d_rtab, &d_seg_cbases, &d_seg_cstart,
                     &d_seg_bstart, &d_c_off, &d_contig_ascii})
         b->release();
+    part_valid = false;         // (d_bstart no longer holds the partition's region layout)
     if (h_report) { (void)hipHostFree(h_report); h_report = nullptr; h_report_words = 0; }
 }
 
