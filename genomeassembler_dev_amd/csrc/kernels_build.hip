@@ -4,9 +4,12 @@
 //
 // What each kernel restates of the reference (paths relative to the reference root):
 //   k_pack_ascii      new surface (the reference keeps std::string)
-//   k_tile_hist /
-//   k_bucket_scatter  lib/DeNovoAssembler.R:109-130 (every k-mer of every read) fused with the first half of the
-//                     de-duplication that lib/DeNovoAssembler.cpp:104-122 does through its hash map
+//   k_bucket_partition
+//                     lib/DeNovoAssembler.R:109-130 (every k-mer of every read) fused with the first half of the
+//                     de-duplication that lib/DeNovoAssembler.cpp:104-122 does through its hash map: one pass into
+//                     per-(segment, bucket) regions
+//   k_tile_hist / k_tile_scan /
+//   k_bucket_scatter  the same in two passes with an exact layout (the retry path of the one above)
 //   k_bucket_dedup    lib/DeNovoAssembler.cpp:104-122 (distinct edges) + multiplicities
 //   k_edge_target / k_edge_multi / k_node_flags
 //                     lib/DeNovoAssembler.cpp:125-169 (in/out degree over distinct edges, branching nodes)
