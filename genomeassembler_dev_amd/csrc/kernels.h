@@ -115,7 +115,8 @@ __global__ void k_edge_multi(GraphView gv, u32 n_segments, u32 chunks, const u32
 template <class K>
 __global__ void k_node_flags(GraphView gv, u32 n_segments, u32 chunks, const u32* claim, u8* eflag, u64* link, u32* clen);
 __global__ void k_edge_next(GraphView gv, u32 n_segments, u32 chunks, const u32* tgt, const u8* eflag, u32* nxt, u64* link);
-__global__ void k_link_jump(GraphView gv, u32 n_segments, u32 chunks, u64* link, const u32* prev_active, u32* active, int jumps);
+__global__ void k_link_jump(GraphView gv, u32 n_segments, u32 chunks, u64* link, const u32* prev_active, u32* active, int jumps, const u32* nxt,
+                            u32* clen);
 __global__ void k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, u64* link, u32* rtab, u32 rshift, u32* flags);
 __global__ void k_rank_lds(GraphView gv, const u32* rtab, u64* link, int max_rounds, u32 rshift, u32 lds_entries, u32* flags);
 __global__ void k_chain_len(const u32* nxt, const u64* link, u32* clen, const u32* n_edges_p);

@@ -1022,7 +1022,8 @@ __global__ void __launch_bounds__(GASM_WG) k_node_flags(GraphView gv, u32 n_segm
         const u32 outd = e - r;
         const bool in_one = claim[r] != GASM_NONE32 && !(eflag[r] & 2);
         eflag[i] = (eflag[i] & 2) | ((!in_one || outd != 1) ? 1 : 0);
-        link[i] = ~0ull;      // "no ancestor" until k_edge_next says otherwise
+        // (no initial link: k_edge_next writes one for every edge — a head's by the head itself, any other edge's by its one
+        // predecessor: its source node has exactly one in-edge, whose target's first and only out-edge it is)
         clen[i] = 0;
     });
 }
@@ -1062,8 +1063,11 @@ __global__ void __launch_bounds__(GASM_WG) k_edge_next(GraphView gv, u32 n_segme
 // `active` (one word per launch, zeroed by the host): set when some link is still short of its head; a launch returns
 // at once when the previous one left it clear.  Members of isolated cycles never finish: the number of launches bounds them.
 #define GASM_JUMP_ILP 4      // links per thread, advanced together: the steps are dependent gathers, so the kernel lives on loads in flight
+// nxt / clen (optional): the launch also does k_chain_len's work for the links it sees final — a chain's last edge publishes
+// the chain's length at its head; the first launch for every edge, later ones for the edges they finish.
 __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segments, u32 chunks, u64* __restrict__ link,
-                                                       const u32* __restrict__ prev_active, u32* __restrict__ active, int jumps) {
+                                                       const u32* __restrict__ prev_active, u32* __restrict__ active, int jumps,
+                                                       const u32* __restrict__ nxt, u32* __restrict__ clen) {
     if (prev_active && *prev_active == 0) return;
     u32 seg, chunk;
     if (!seg_chunk(n_segments, chunks, &seg, &chunk)) return;       // a segment's links stay in one XCD's L2
@@ -1081,6 +1085,14 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
             act[q] = (u32)(l[q] >> 32) != GASM_NONE32 && !(l[q] & GASM_LINK_DONE);
         }
         const bool mine = act[0] || act[1] || act[2] || act[3];
+        u32 tail = 0;                                 // bit q: edge q is the last of its chain and this launch owes it the length
+        if (nxt) {
+#pragma unroll
+            for (int q = 0; q < GASM_JUMP_ILP; ++q) {
+                const u32 i = i0 + q * GASM_WG;
+                if (i < hi && (act[q] || !prev_active) && nxt[i] == GASM_NONE32) tail |= 1u << q;
+            }
+        }
         for (int j = 0; j < jumps && (act[0] || act[1] || act[2] || act[3]); ++j) {
             u64 la[GASM_JUMP_ILP];
 #pragma unroll
@@ -1101,6 +1113,10 @@ __global__ void __launch_bounds__(GASM_WG) k_link_jump(GraphView gv, u32 n_segme
                 if (l[q] & GASM_LINK_DONE) act[q] = false;
             }
         }
+#pragma unroll
+        for (int q = 0; q < GASM_JUMP_ILP; ++q)
+            if (((tail >> q) & 1u) && (u32)(l[q] >> 32) != GASM_NONE32 && (l[q] & GASM_LINK_DONE))
+                clen[(u32)(l[q] >> 32)] = ((u32)l[q] & 0x7FFFFFFFu) + 1;
         if (!mine) continue;
         bool open = false;
 #pragma unroll

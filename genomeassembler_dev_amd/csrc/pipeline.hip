@@ -672,7 +672,8 @@ static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
         // least, so two launches cover any segment of this size, and the second normally returns at once)
         const int jumps = 255, launches = 2;
         for (int r = 0; r < launches; ++r)
-            GLAUNCH(ctx, "k_link_jump", k_link_jump, seg_grid(jchunks, S), dim3(GASM_WG), 0, gv, S, jchunks, bs.d_link.as<u64>(), r ? act + r - 1 : nullptr, act + r, jumps);
+            GLAUNCH(ctx, "k_link_jump", k_link_jump, seg_grid(jchunks, S), dim3(GASM_WG), 0, gv, S, jchunks, bs.d_link.as<u64>(), r ? act + r - 1 : nullptr, act + r, jumps,
+                    bs.d_nxt.as<u32>(), bs.d_clen.as<u32>());         // (+ the chains' lengths: k_chain_len's work)
     } else {
         // whole-GPU launches of `jumps` doubling steps each; a launch returns at once when its predecessor found every chain done
         // (spans grow by at least jumps + 1 = 5 per launch: log2(5) > 2.3 rounds' worth)
@@ -682,11 +683,13 @@ static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
         const int jumps = 4, launches = (rounds * 10 + 22) / 23 + 1;
         if (launches > 40) { gasm_set_error("segment too large for the list-ranking flags"); return GASM_ERR_CAPACITY; }
         for (int r = 0; r < launches; ++r)
-            GLAUNCH(ctx, "k_link_jump", k_link_jump, seg_grid(jchunks, S), dim3(GASM_WG), 0, gv, S, jchunks, bs.d_link.as<u64>(), r ? act + r - 1 : nullptr, act + r, jumps);
+            GLAUNCH(ctx, "k_link_jump", k_link_jump, seg_grid(jchunks, S), dim3(GASM_WG), 0, gv, S, jchunks, bs.d_link.as<u64>(), r ? act + r - 1 : nullptr, act + r, jumps,
+                    (const u32*)nullptr, (u32*)nullptr);
     }
     const u32 grid_all = (u32)std::min<u64>(ceil_div_u64((u64)est * S, GASM_WG), (u64)ctx->n_cu * 64);
-    GLAUNCH(ctx, "k_chain_len", k_chain_len, dim3(std::max(1u, grid_all)), dim3(GASM_WG), 0, bs.d_nxt.as<u32>(), bs.d_link.as<u64>(),
-            bs.d_clen.as<u32>(), gv.dstart + (size_t)S * nb);
+    if (!bs.ranked_in_lds)      // (the LDS path's k_link_jump launches publish the chains' lengths themselves)
+        GLAUNCH(ctx, "k_chain_len", k_chain_len, dim3(std::max(1u, grid_all)), dim3(GASM_WG), 0, bs.d_nxt.as<u32>(), bs.d_link.as<u64>(),
+                bs.d_clen.as<u32>(), gv.dstart + (size_t)S * nb);
     GLAUNCH(ctx, "k_contig_scan", k_contig_scan, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
             bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), d_seg_ncontig, bs.d_seg_cbases.as<u64>());
     // segment directories of the contigs + the report (ticket last)
