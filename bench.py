@@ -53,8 +53,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)      # (a step is ~1.2 ms: 20 of them were over before the clocks had settled)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="segments", choices=["segments", "pooled"])
     ap.add_argument("--segments-per-gpu", type=int, default=0)
