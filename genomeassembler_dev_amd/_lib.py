@@ -111,6 +111,16 @@ SYMBOLS = {
     "gasm_pool_fetch_distinct": (_int, [_vp, _PP, _PP, _PP, C.POINTER(_int)]),
     "gasm_pool_fetch_contigs": (_int, [_vp, _PP, _PP, _PP]),
     "gasm_pool_fetch_scores": (_int, [_vp, _PP, _PP, _PP, _PP, _PP]),
+    "gasm_comm_unique_id": (_int, [_vp]),
+    "gasm_comm_create": (_int, [_vp, _vp, _int, _int, _PP]),
+    "gasm_comm_create_virtual": (_int, [_vp, _int, _PP]),
+    "gasm_comm_destroy": (None, [_vp]),
+    "gasm_comm_world": (_int, [_vp]),
+    "gasm_comm_rank": (_int, [_vp]),
+    "gasm_comm_stage": (_int, [_vp]),
+    "gasm_pool_bucket_owner": (_int, [_u32, _int, _u32, _vp]),
+    "gasm_pool_segment_bounds": (_int, [_u32, _u32, _vp]),
+    "gasm_pool_exchange_build": (_int, [_vp, _vp, _u32, _int, _int, _int, _vp, _vp]),
     "gasm_profile_enable": (_int, [_vp, _int]),
     "gasm_profile_filter": (_int, [_vp, C.c_char_p]),
     "gasm_profile_reset": (_int, [_vp]),
@@ -120,19 +130,53 @@ SYMBOLS = {
 _lib = None
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process, whatever the import order.  PyTorch-ROCm ships its own libamdhip64.so (soname
+    libamdhip64.so.7, the soname libgasm.so asks for) and its own librccl.so.  If libgasm were loaded first, the loader would
+    take ROCm's copy for it and later a second one (torch's, by path) for torch — two runtimes, and the one that initialises
+    the GPU second finds no device (round 2: "No HIP GPUs are available" after 55 tests).  So where torch is installed its
+    copy is mapped BEFORE libgasm, imported or not: libgasm's NEEDED entry then resolves to it by soname, and a later
+    `import torch` finds its own file already mapped.  Without torch on the machine ROCm's copy is the only one there is."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        base = os.path.dirname(sys.modules["torch"].__file__)
+    else:
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is None or not spec.origin:
+            return
+        base = os.path.dirname(spec.origin)
+    for name in ("libamdhip64.so", "librccl.so"):
+        path = os.path.join(base, "lib", name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path)       # (RTLD_LOCAL: the loader matches NEEDED entries by soname in any case; RTLD_GLOBAL on librccl ends in a double free at exit)
+            except OSError as e:       # a torch build without ROCm libraries: nothing to share
+                if name == "libamdhip64.so":
+                    raise RuntimeError(f"PyTorch's HIP runtime at {path} could not be mapped ({e}); libgasm would bring a "
+                                       "second runtime into a process that later imports torch") from e
+
+
+def hip_runtimes_mapped():
+    """paths of the libamdhip64 copies mapped into this process (the guard's check: there must be exactly one)"""
+    out = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                out.add(line.split()[-1])
+    return sorted(out)
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc, gfx950).  genomeassembler_dev_amd has no CPU fallback.")
-        # One HIP runtime per process: PyTorch-ROCm ships its own copy, and whichever copy initialises the GPU second finds
-        # no device.  When torch is part of the program (pooled builds, bench.py) it goes first.
-        import sys
-        if "torch" in sys.modules:
-            torch = sys.modules["torch"]
-            if torch.cuda.is_available():
-                torch.cuda.init()
+        _one_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(L, name)

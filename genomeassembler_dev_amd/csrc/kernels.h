@@ -133,7 +133,7 @@ __global__ void k_pack_runs(const K* keys, const u32* mult, const u64* bstart, c
                             u32* out_cnt);
 template <class K, int TBL>
 __global__ void k_bucket_merge(const K* in_keys, const u32* in_cnt, const u64* run_off, const u32* run_len, u32 n_src, K* out_keys, u32* out_cnt,
-                               const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits);
+                               const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits, const u64* src_base);
 __global__ void k_repack_reads(const u64* src, const u64* dir, u64* words_out);
 __global__ void k_piece_positions(const u64* piece_first, const u64* piece_word_off, u32 n_pieces, u64 n_reads, u32 fixed_len, u64* pos);
 __global__ void k_slice_last(const u32* a, const u64* off, u32 n, u32* out);
@@ -185,3 +185,13 @@ __global__ void k_path_ks(PathSet ps, const u32* poscnt, const int32_t* drow, in
 __global__ void k_cover_mark(const long long* start, const long long* len, u64 n, long long seq_len, int* diff);
 __global__ void k_cover_count(const int* diff, long long seq_len, unsigned long long* covered);
 __global__ void k_prob_dist(PathSet ps, const double* dprob, int kmer, const u64* pd_off, double* out, u32 n_paths);
+
+// ---- kernels_pool.hip: exchange plans (exchange.hip)
+__global__ void k_x_flag_word(const u32* flags, u32* row_tail);
+__global__ void k_x1_plan(const u32* lens_all, u64 stride, u32 nbt, const u32* order, const u32* dst_first, const u32* mine, u32 n_mine, u32 W, u32 r, u32 limit,
+                          u64* send_off, u64* send_tot, u64* run_off, u32* run_len, u64* recv_tot, u64* bstart, u32* flags_or);
+__global__ void k_x2_fill(u32* G, u32 nbt, const u32* mine, u32 n_mine, const u32* bucket_d, const u32* flags);
+__global__ void k_x2_plan(const u32* G, const u16* own1, u32 W, u32 r, u32 gb_lo, u32 n_out, int bbits, const u32* mine, u32 n_mine, const u32* seg_first,
+                          u64* send_off, u64* send_tot, u64* run_off, u32* run_len, u64* recv_tot, u64* bstart, u64* info);
+__global__ void k_x_report(const u64* send_tot, const u64* recv_tot, u32 W, const u64* info, u32 n_info, const u32* flags_or, u64* report, u64 ticket);
+__global__ void k_x_add_u32(u32* acc, const u32* v, u64 n);

@@ -87,7 +87,7 @@ template <class K, int TBL>
 __global__ void __launch_bounds__(GASM_WG, TBL == 4096 ? 2 : 3)      // (LDS: 56 KB / 44 KB per workgroup)
 k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, const u64* __restrict__ run_off, const u32* __restrict__ run_len,
                u32 n_src, K* __restrict__ out_keys, u32* __restrict__ out_cnt, const u64* __restrict__ bstart, u32* __restrict__ bucket_d,
-               u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits) {
+               u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, const u64* __restrict__ src_base) {
     constexpr int LIMIT = TBL / 16 * 11;
     constexpr int BINS = TBL / 4;
     constexpr int LOG_SETS = (TBL == 4096 ? 12 : 11) - 1;
@@ -105,7 +105,7 @@ k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, co
         for (u32 s = 0; s < n_src; ++s) if (run_len[(u64)j * n_src + s]) { ++n_nonempty; only = s; }
         if (n_nonempty <= 1) {
             const u32 len = n_nonempty ? run_len[(u64)j * n_src + only] : 0u;
-            const u64 off = n_nonempty ? run_off[(u64)j * n_src + only] : 0ull;
+            const u64 off = n_nonempty ? run_off[(u64)j * n_src + only] + (src_base ? src_base[only] : 0ull) : 0ull;
             if (len > (u32)LIMIT) {
                 for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)j * (BINS + 1) + i] = 0;
                 if (threadIdx.x == 0) { atomicOr(overflow, 1u); bucket_d[j] = 0; }
@@ -132,7 +132,7 @@ k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, co
     if (threadIdx.x == 0) { s_tmp[4] = 0; s_tmp[5] = 0; s_tmp[6] = 0; }
     __syncthreads();
     for (u32 s = 0; s < n_src; ++s) {
-        const u64 off = run_off[(u64)j * n_src + s];
+        const u64 off = run_off[(u64)j * n_src + s] + (src_base ? src_base[s] : 0ull);    // (src_base: run_off counts from the source's first record)
         const u32 len = run_len[(u64)j * n_src + s];
         for (u32 i = threadIdx.x; i < len; i += GASM_WG) {
             if (__hip_atomic_load(&s_tmp[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > (u32)LIMIT) { s_tmp[5] = 1; break; }
@@ -156,8 +156,8 @@ k_bucket_merge(const K* __restrict__ in_keys, const u32* __restrict__ in_cnt, co
     for (u32 i = threadIdx.x; i < d; i += GASM_WG) { out_keys[beg + i] = t_key[i]; out_cnt[beg + i] = t_cnt[i]; }
     if (threadIdx.x == 0) bucket_d[j] = d;
 }
-template __global__ void k_bucket_merge<u64, 4096>(const u64*, const u32*, const u64*, const u32*, u32, u64*, u32*, const u64*, u32*, u32*, u16*, int);
-template __global__ void k_bucket_merge<K128, 2048>(const K128*, const u32*, const u64*, const u32*, u32, K128*, u32*, const u64*, u32*, u32*, u16*, int);
+template __global__ void k_bucket_merge<u64, 4096>(const u64*, const u32*, const u64*, const u32*, u32, u64*, u32*, const u64*, u32*, u32*, u16*, int, const u64*);
+template __global__ void k_bucket_merge<K128, 2048>(const K128*, const u32*, const u64*, const u32*, u32, K128*, u32*, const u64*, u32*, u32*, u16*, int, const u64*);
 
 // Piece blockIdx.y: words_out[woff + w] = the 32 bases from base b0 + 32 w of the packed stream `src`, zero-filled past base
 // b1, for w < ceil((b1 - b0) / 32); dir = {b0, b1, woff} per piece.  One launch for all pieces (a launch per segment was
@@ -188,4 +188,154 @@ __global__ void __launch_bounds__(GASM_WG) k_piece_positions(const u64* __restri
 __global__ void __launch_bounds__(GASM_WG) k_slice_last(const u32* __restrict__ a, const u64* __restrict__ off, u32 n, u32* __restrict__ out) {
     const u32 s = blockIdx.x * GASM_WG + threadIdx.x;
     if (s < n) out[s] = off[s + 1] > off[s] ? a[off[s + 1] - 1] : 0u;
+}
+
+// ================================================================================================================
+// Exchange plans (exchange.hip): everything the host layer of round 2 computed with numpy between two all-to-alls — which
+// run goes where, at which record offset it lands, how many records every peer gets — is computed here, on the device,
+// from run-length tables that never leave it.  The host sees one small report per exchange (the per-peer totals it must
+// hand to ncclSend / ncclRecv, which take their counts from the host).
+// ================================================================================================================
+// Exclusive scan of get(0..n) with one workgroup of 1024 threads (running carry, 8 entries per thread and pass);
+// put(i, exclusive prefix) for every i; returns the total to every thread.  s_wave: 16 u64 of LDS.
+template <class G, class P>
+__device__ __forceinline__ u64 wg_scan_seq(u32 n, u64* s_wave, G&& get, P&& put) {
+    const u32 ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    u64 carry = 0;
+    for (u32 base = 0; base < n; base += 8192) {
+        const u32 i0 = base + threadIdx.x * 8;
+        u32 v[8];
+        u64 sum = 0;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) { v[q] = i0 + q < n ? get(i0 + q) : 0u; sum += v[q]; }
+        u64 inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u64 o = __shfl_up(inc, d, 64);
+            if ((int)ln >= d) inc += o;
+        }
+        if (ln == 63) s_wave[wv] = inc;
+        __syncthreads();
+        u64 before = 0, tot = 0;
+#pragma unroll
+        for (u32 w = 0; w < 16; ++w) { const u64 t = s_wave[w]; if (w < wv) before += t; tot += t; }
+        __syncthreads();
+        u64 ex = carry + before + inc - sum;
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) {
+            if (i0 + q < n) put(i0 + q, ex);
+            ex += v[q];
+        }
+        carry += tot;
+    }
+    return carry;
+}
+
+// the row a rank contributes to the all-gather of exchange 1: its NBT run lengths (already in place) + its flag word
+__global__ void k_x_flag_word(const u32* __restrict__ flags, u32* __restrict__ row_tail) { if (threadIdx.x == 0) *row_tail = flags[0]; }
+
+// Exchange 1 (every bucket's runs to the bucket's owner), rank r of W.  lens_all[s * stride + gb] = rank s's run length of
+// bucket gb, [.. + nbt] = rank s's flag word.  order[0..nbt) = the buckets sorted by owner (dst_first[d] .. dst_first[d+1]:
+// the buckets rank d merges, increasing); mine[0..n_mine) = the buckets this rank merges.
+//   block s < W : what arrives from rank s — run_len[j * W + s], run_off[j * W + s] (records from the source's first), recv_tot[s]
+//   block W     : what leaves — send_off[i] for order[i], send_tot[d]; flags_or = OR of all ranks' flag words
+//   block W + 1 : capacity of the merged runs — bstart[j] = sum over j' < j of min(sum_s len, limit)
+__global__ void __launch_bounds__(1024) k_x1_plan(const u32* __restrict__ lens_all, u64 stride, u32 nbt, const u32* __restrict__ order,
+                                                  const u32* __restrict__ dst_first, const u32* __restrict__ mine, u32 n_mine, u32 W, u32 r, u32 limit,
+                                                  u64* __restrict__ send_off, u64* __restrict__ send_tot, u64* __restrict__ run_off,
+                                                  u32* __restrict__ run_len, u64* __restrict__ recv_tot, u64* __restrict__ bstart,
+                                                  u32* __restrict__ flags_or) {
+    __shared__ u64 s_wave[16];
+    const u32 b = blockIdx.x;
+    if (b < W) {
+        const u32* row = lens_all + (u64)b * stride;
+        const u64 tot = wg_scan_seq(n_mine, s_wave, [&](u32 j) { return row[mine[j]]; },
+                                    [&](u32 j, u64 ex) { run_off[(u64)j * W + b] = ex; run_len[(u64)j * W + b] = row[mine[j]]; });
+        if (threadIdx.x == 0) recv_tot[b] = tot;
+    } else if (b == W) {
+        const u32* row = lens_all + (u64)r * stride;
+        const u64 tot = wg_scan_seq(nbt, s_wave, [&](u32 i) { return row[order[i]]; }, [&](u32 i, u64 ex) { send_off[i] = ex; });
+        if (threadIdx.x == 0) send_off[nbt] = tot;
+        __syncthreads();
+        if (threadIdx.x < W) send_tot[threadIdx.x] = send_off[dst_first[threadIdx.x + 1]] - send_off[dst_first[threadIdx.x]];
+        if (threadIdx.x == 0) {
+            u32 f = 0;
+            for (u32 s = 0; s < W; ++s) f |= lens_all[(u64)s * stride + nbt];
+            *flags_or = f;
+        }
+    } else {
+        const u64 tot = wg_scan_seq(n_mine, s_wave,
+                                    [&](u32 j) {
+                                        u64 sum = 0;
+                                        for (u32 s = 0; s < W; ++s) sum += lens_all[(u64)s * stride + mine[j]];
+                                        return (u32)(sum < limit ? sum : limit);
+                                    },
+                                    [&](u32 j, u64 ex) { bstart[j] = ex; });
+        if (threadIdx.x == 0) bstart[n_mine] = tot;
+    }
+}
+
+// the table every rank contributes to the all-reduce of exchange 2: merged length of the buckets it owns, zero elsewhere
+// (the table is zeroed by a fill before), + its flag word at [nbt]
+__global__ void __launch_bounds__(GASM_WG) k_x2_fill(u32* __restrict__ G, u32 nbt, const u32* __restrict__ mine, u32 n_mine,
+                                                     const u32* __restrict__ bucket_d, const u32* __restrict__ flags) {
+    const u32 j = blockIdx.x * GASM_WG + threadIdx.x;
+    if (j < n_mine) G[mine[j]] = bucket_d[j];
+    if (j == 0) G[nbt] = flags[0];
+}
+
+// Exchange 2 (the merged runs to their segment's owner), rank r of W.  G[gb] = merged length of bucket gb (all-reduced),
+// own1[gb] = the rank that merged it; this rank's segments are [seg_first[r], seg_first[r + 1]) = buckets gb_lo .. gb_lo + n_out.
+//   block s < W : run_len2[i * W + s] = (own1[gb_lo + i] == s) ? G : 0, run_off2 from the source's first record, recv_tot[s]
+//   block W     : send_off2[j] of this rank's merged run j (bucket mine[j]); send_tot[d] (runs bound for one rank are consecutive)
+//   block W + 1 : bstart2[i] (exact), the rank's distinct k-mers in all (info[0]) and of its largest segment (info[1])
+__global__ void __launch_bounds__(1024) k_x2_plan(const u32* __restrict__ G, const u16* __restrict__ own1, u32 W, u32 r, u32 gb_lo, u32 n_out, int bbits,
+                                                  const u32* __restrict__ mine, u32 n_mine, const u32* __restrict__ seg_first,
+                                                  u64* __restrict__ send_off, u64* __restrict__ send_tot, u64* __restrict__ run_off,
+                                                  u32* __restrict__ run_len, u64* __restrict__ recv_tot, u64* __restrict__ bstart, u64* __restrict__ info) {
+    __shared__ u64 s_wave[16];
+    __shared__ u32 s_max;
+    const u32 b = blockIdx.x;
+    if (b < W) {
+        const u64 tot = wg_scan_seq(n_out, s_wave, [&](u32 i) { return own1[gb_lo + i] == b ? G[gb_lo + i] : 0u; },
+                                    [&](u32 i, u64 ex) { run_off[(u64)i * W + b] = ex; run_len[(u64)i * W + b] = own1[gb_lo + i] == b ? G[gb_lo + i] : 0u; });
+        if (threadIdx.x == 0) recv_tot[b] = tot;
+    } else if (b == W) {
+        const u64 tot = wg_scan_seq(n_mine, s_wave, [&](u32 j) { return G[mine[j]]; }, [&](u32 j, u64 ex) { send_off[j] = ex; });
+        if (threadIdx.x == 0) send_off[n_mine] = tot;
+        __syncthreads();
+        if (threadIdx.x < W) {
+            const u32 d = threadIdx.x;
+            const u32 lo = lower_bound_dev<u32>(mine, 0, n_mine, seg_first[d] << bbits), hi = lower_bound_dev<u32>(mine, 0, n_mine, seg_first[d + 1] << bbits);
+            send_tot[d] = send_off[hi] - send_off[lo];
+        }
+    } else {
+        if (threadIdx.x == 0) s_max = 0;
+        const u64 tot = wg_scan_seq(n_out, s_wave, [&](u32 i) { return G[gb_lo + i]; }, [&](u32 i, u64 ex) { bstart[i] = ex; });
+        const u32 nb = 1u << bbits;
+        u32 mx = 0;
+        for (u32 s = threadIdx.x; s < n_out / nb; s += 1024) {
+            u64 d = 0;
+            for (u32 q = 0; q < nb; ++q) d += G[gb_lo + s * nb + q];
+            mx = max(mx, (u32)min(d, (u64)0xFFFFFFFFu));
+        }
+        atomicMax(&s_max, mx);
+        __syncthreads();
+        if (threadIdx.x == 0) { bstart[n_out] = tot; info[0] = tot; info[1] = s_max; }
+    }
+}
+
+// The report of an exchange plan: W send totals, W receive totals, up to four more words, then the ticket (pinned memory).
+__global__ void __launch_bounds__(64) k_x_report(const u64* __restrict__ send_tot, const u64* __restrict__ recv_tot, u32 W, const u64* __restrict__ info, u32 n_info,
+                                                 const u32* __restrict__ flags_or, u64* __restrict__ report, u64 ticket) {
+    for (u32 i = threadIdx.x; i < W; i += 64) { report[i] = send_tot[i]; report[W + i] = recv_tot[i]; }
+    if (threadIdx.x < n_info) report[2 * W + threadIdx.x] = info[threadIdx.x];
+    if (threadIdx.x == 0) report[2 * W + 4] = flags_or ? (u64)*flags_or : 0ull;
+    __threadfence_system();
+    if (threadIdx.x == 0) report[2 * W + 5] = ticket;
+}
+
+// sum of n u32 arrays, element by element (the all-reduce of the virtual communicator)
+__global__ void __launch_bounds__(GASM_WG) k_x_add_u32(u32* __restrict__ acc, const u32* __restrict__ v, u64 n) {
+    for (u64 i = (u64)blockIdx.x * GASM_WG + threadIdx.x; i < n; i += (u64)gridDim.x * GASM_WG) acc[i] += v[i];
 }

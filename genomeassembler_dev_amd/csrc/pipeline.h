@@ -163,3 +163,7 @@ int pipeline_ks(gasm_ctx* ctx, DevPaths& dp, ScoreState& ss, const ScoreTable& t
 // contig_frac_len (lib/DeNovoAssembler.R:432-445)
 int pipeline_coverage(gasm_ctx* ctx, const long long* start, const long long* len, u64 n, long long seq_len, double* percent);
 int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 target_len, bool infix, std::vector<int32_t>& lev, bool* done);
+
+// wait for `ticket` to appear at `word` (pinned memory written last by a kernel of the ctx stream); spin, then poll with a deadline
+int gasm_wait_word32(gasm_ctx* ctx, const volatile u32* word, u32 ticket);
+int gasm_wait_word64(gasm_ctx* ctx, const volatile u64* word, u64 ticket);

@@ -2,6 +2,7 @@
 // where a size is needed to allocate the next stage (distinct count, contig bytes) and at fetch time.
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include "pipeline.h"
 
 #include <algorithm>
@@ -59,17 +60,34 @@ static int env_int(const char* name, int dflt) { const char* v = getenv(name); r
 
 // Wait for a report a kernel writes into pinned host memory: the kernel's last store is `ticket` at `word`.  Spinning on
 // that word costs a few microseconds; waking up from hipStreamSynchronize costs 15-20 us (more on a busy host) — twice
-// per build, with the GPU idle meanwhile.  After ~2 ms of spinning (a large batch) the thread sleeps in the stream wait.
-static int wait_report(gasm_ctx* ctx, const volatile u32* word, u32 ticket) {
+// per build, with the GPU idle meanwhile.  After ~2 ms of spinning (a large batch) the thread polls the stream with short
+// sleeps, up to a deadline (GASM_WAIT_TIMEOUT_S, default 300 s): a kernel that never finishes becomes an error, not a hang.
+template <class T>
+static int wait_word(gasm_ctx* ctx, const volatile T* word, T ticket) {
     const auto t0 = std::chrono::steady_clock::now();
     for (u32 spin = 0;; ++spin) {
         if (*word == ticket) { std::atomic_thread_fence(std::memory_order_acquire); return GASM_OK; }
         if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    static const double limit_s = [] { const char* v = getenv("GASM_WAIT_TIMEOUT_S"); const double x = v && *v ? atof(v) : 300.0; return x > 0 ? x : 300.0; }();
+    for (;;) {
+        if (*word == ticket) { std::atomic_thread_fence(std::memory_order_acquire); return GASM_OK; }
+        const hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) break;                       // the stream has drained: the report is there or never comes
+        if (q != hipErrorNotReady) { gasm_set_error("the stream failed while a report was awaited: %s", hipGetErrorString(q)); return GASM_ERR_HIP; }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit_s) {
+            gasm_set_error("no report from the device within %.0f s (GASM_WAIT_TIMEOUT_S): a kernel hangs or the GPU is lost", limit_s);
+            return GASM_ERR_HIP;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
     if (*word != ticket) { gasm_set_error("a kernel finished without writing its report"); return GASM_ERR_HIP; }
+    std::atomic_thread_fence(std::memory_order_acquire);
     return GASM_OK;
 }
+int gasm_wait_word32(gasm_ctx* ctx, const volatile u32* word, u32 ticket) { return wait_word<u32>(ctx, word, ticket); }
+int gasm_wait_word64(gasm_ctx* ctx, const volatile u64* word, u64 ticket) { return wait_word<u64>(ctx, word, ticket); }
+static int wait_report(gasm_ctx* ctx, const volatile u32* word, u32 ticket) { return wait_word<u32>(ctx, word, ticket); }
 static u32 next_ticket() { static std::atomic<u32> t{1}; u32 v = t.fetch_add(1); return v ? v : t.fetch_add(1); }
 
 // grid of the segment-major kernels (seg_chunk, device_utils.h): 8 x chunks x ceil(S / 8) workgroups

@@ -17,24 +17,7 @@
 // rank); the library sees only bucket lists and run directories, so outputs cannot depend on the number of ranks.
 #include <algorithm>
 
-#include "pipeline.h"
-
-struct gasm_pool {
-    gasm_ctx* ctx = nullptr;
-    DevReads rd;            // this rank's reads of all segments
-    BuildState bs;          // current runs (d_keys / d_mult / d_bstart / d_bucket_d), later the rank's graph
-    u32 n_runs = 0;         // buckets the current runs cover
-    std::vector<u32> h_len; // their lengths
-    DevReads own;           // the reads of the rank's own segments (gasm_pool_set_reads)
-    u32 n_local = 0;
-    bool graphed = false, reads_set = false;
-    DevPaths dp;
-    ScoreTable tb;
-    ScoreState ss;
-    bool table_set = false, paths_ready = false;
-    std::vector<double> table_copy;
-    DBuf d_list, d_off, d_roff, d_rlen;
-};
+#include "pool.h"
 
 #define POOL_GUARD_BEGIN try {
 #define POOL_GUARD_END                                                         \
@@ -59,6 +42,63 @@ static int read_lens(gasm_pool* p, u32 n) {
     HIPCHK(hipMemcpyAsync(fl, p->bs.d_flags.p, 8, hipMemcpyDeviceToHost, p->ctx->stream));
     HIPCHK(hipStreamSynchronize(p->ctx->stream));
     return (int)(fl[0] & 3u);   // bit 0 = a bucket overflowed its table, bit 1 = a bucket outgrew its region (single-pass partition)
+}
+
+int pool_graph_launch(gasm_pool* p, u32 S, u64 D, u64 maxD) {
+    gasm_ctx* ctx = p->ctx;
+    BuildState& bs = p->bs;
+    HIPCHK(hipSetDevice(ctx->device));
+    p->n_local = S;
+    p->own.n_segments = S;
+    if (!p->reads_set) {
+        p->own.n_reads = 0; p->own.fixed_len = p->rd.fixed_len; p->own.min_len = p->own.max_len = p->rd.fixed_len;
+        p->own.h_seg_read_off.assign((size_t)S + 1, 0);
+        p->own.h_seg_empty.assign(S, 0);
+    }
+    bs.fetched_distinct = bs.fetched_contigs = false;
+    bs.h_dstart.assign((size_t)S + 1, 0); bs.h_seg_cstart.assign((size_t)S + 1, 0); bs.h_seg_bstart.assign((size_t)S + 1, 0);
+    bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
+    bs.D_cap = D; bs.maxD_cap = maxD; bs.maxD_est = (u32)std::max<u64>(1, std::min<u64>(maxD, 0xFFFFFFF0ull));
+    bs.n_kmers = D;                 // (> 0 iff there is a graph: what the scorer asks)
+    bs.have_actual = false; bs.rank_global = false;
+    bs.pending = false;
+    p->graphed = true; p->paths_ready = false; p->ss.launched = false; p->ss.valid = false; p->scored = false;
+    if (S == 0) return GASM_OK;
+    GCHK(bs.d_dstart.ensure(((size_t)p->n_runs + 2) * 4));
+    GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), p->n_runs);
+    GCHK(launch_graph(ctx, S, bs));
+    return GASM_OK;
+}
+
+int pool_score_launch(gasm_pool* p, int kmer, const double* table, bool wait_for_build) {
+    if (!p->graphed || !p->reads_set) { gasm_set_error("scoring needs the rank's graph and the reads of its segments first"); return GASM_ERR_STATE; }
+    gasm_ctx* ctx = p->ctx;
+    if (!p->table_set || memcmp(p->table_copy.data(), table, GASM_TABLE_ROWS * sizeof(double)) != 0) {
+        GCHK(p->tb.set_standard(ctx, table));
+        p->table_copy.assign(table, table + GASM_TABLE_ROWS);
+        p->table_set = true;
+    }
+    // through the graph (every read holds a k-mer) the scoring needs no size from the host and is queued behind the build as it is
+    const bool through_graph = p->n_local && pipeline_score_uses_graph(p->own, p->bs);
+    if (wait_for_build || !through_graph) GCHK(pipeline_build_finish_n(ctx, nullptr, p->n_local, p->bs, nullptr));
+    if (!p->paths_ready) {
+        GCHK(pipeline_contig_paths(ctx, p->own, p->bs, p->dp));
+        p->paths_ready = true;
+    }
+    if (!p->bs.pending) pipeline_contig_paths_host(p->own, p->bs, p->dp);
+    GCHK(pipeline_score_launch(ctx, p->own, p->dp, kmer, p->tb, false, false, p->ss, &p->bs));
+    p->scored = true; p->score_kmer = kmer;
+    return GASM_OK;
+}
+
+int pool_finish(gasm_pool* p) {
+    bool rebuilt = false;
+    GCHK(pipeline_build_finish_n(p->ctx, nullptr, p->n_local, p->bs, &rebuilt));
+    if (rebuilt && p->scored) {
+        p->paths_ready = false;
+        GCHK(pool_score_launch(p, p->score_kmer, p->table_copy.data(), true));
+    }
+    return GASM_OK;
 }
 
 extern "C" {
@@ -194,11 +234,11 @@ int gasm_pool_merge_runs(gasm_pool* p, uint32_t n_out, uint32_t n_src, const uin
         if (bs.words == 1) {
             GLAUNCH(ctx, "k_bucket_merge", (k_bucket_merge<u64, 4096>), dim3(n_out), dim3(GASM_WG), 0, static_cast<const u64*>(d_keys_in),
                     static_cast<const u32*>(d_counts_in), p->d_roff.as<u64>(), p->d_rlen.as<u32>(), n_src, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * bs.k - bs.bbits);
+                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * bs.k - bs.bbits, (const u64*)nullptr);
         } else {
             GLAUNCH(ctx, "k_bucket_merge", (k_bucket_merge<K128, 2048>), dim3(n_out), dim3(GASM_WG), 0, static_cast<const K128*>(d_keys_in),
                     static_cast<const u32*>(d_counts_in), p->d_roff.as<u64>(), p->d_rlen.as<u32>(), n_src, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
-                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * bs.k - bs.bbits);
+                    bs.d_bstart.as<u64>(), bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * bs.k - bs.bbits, (const u64*)nullptr);
         }
     }
     p->n_runs = n_out;
@@ -217,21 +257,8 @@ int gasm_pool_merge_runs(gasm_pool* p, uint32_t n_out, uint32_t n_src, const uin
 int gasm_pool_graph(gasm_pool* p, uint32_t n_local_segments) {
     POOL_GUARD_BEGIN
     if (!p) { gasm_set_error("pool is null"); return GASM_ERR_INVALID; }
-    gasm_ctx* ctx = p->ctx;
-    BuildState& bs = p->bs;
-    const u32 S = n_local_segments, nb = 1u << bs.bbits;
+    const u32 S = n_local_segments, nb = 1u << p->bs.bbits;
     if ((u64)S * nb != p->n_runs) { gasm_set_error("the current runs cover %u buckets, %u segments need %llu", p->n_runs, S, (unsigned long long)S * nb); return GASM_ERR_STATE; }
-    HIPCHK(hipSetDevice(ctx->device));
-    p->n_local = S;
-    p->own.n_segments = S;
-    if (!p->reads_set) {
-        p->own.n_reads = 0; p->own.fixed_len = p->rd.fixed_len; p->own.min_len = p->own.max_len = p->rd.fixed_len;
-        p->own.h_seg_read_off.assign((size_t)S + 1, 0);
-        p->own.h_seg_empty.assign(S, 0);
-    }
-    bs.fetched_distinct = bs.fetched_contigs = false;
-    bs.h_dstart.assign((size_t)S + 1, 0); bs.h_seg_cstart.assign((size_t)S + 1, 0); bs.h_seg_bstart.assign((size_t)S + 1, 0);
-    bs.d_total = 0; bs.n_contigs = 0; bs.contig_bases = 0;
     // sizes are exact here: the merged run lengths are on the host
     u64 D = 0, maxD = 0;
     for (u32 s = 0; s < S; ++s) {
@@ -239,16 +266,7 @@ int gasm_pool_graph(gasm_pool* p, uint32_t n_local_segments) {
         for (u32 b = 0; b < nb; ++b) d += p->h_len[(size_t)s * nb + b];
         D += d; maxD = std::max(maxD, d);
     }
-    bs.D_cap = D; bs.maxD_cap = maxD; bs.maxD_est = (u32)std::max<u64>(1, maxD);
-    bs.n_kmers = D;                 // (> 0 iff there is a graph: what the scorer asks)
-    bs.have_actual = false; bs.rank_global = false;
-    bs.pending = false;
-    p->graphed = true; p->paths_ready = false; p->ss.launched = false; p->ss.valid = false;
-    if (S == 0) return GASM_OK;
-    GCHK(bs.d_dstart.ensure(((size_t)p->n_runs + 2) * 4));
-    GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), p->n_runs);
-    GCHK(launch_graph(ctx, S, bs));
-    return GASM_OK;
+    return pool_graph_launch(p, S, D, maxD);
     POOL_GUARD_END
 }
 
@@ -337,20 +355,7 @@ int gasm_pool_set_reads(gasm_pool* p, const void* d_words, uint64_t n_words, uin
 int gasm_pool_score(gasm_pool* p, int kmer, const double* table) {
     POOL_GUARD_BEGIN
     if (!p || !table) { gasm_set_error("gasm_pool_score: null argument"); return GASM_ERR_INVALID; }
-    if (!p->graphed || !p->reads_set) { gasm_set_error("gasm_pool_score needs gasm_pool_graph and gasm_pool_set_reads first"); return GASM_ERR_STATE; }
-    gasm_ctx* ctx = p->ctx;
-    if (!p->table_set || memcmp(p->table_copy.data(), table, GASM_TABLE_ROWS * sizeof(double)) != 0) {
-        GCHK(p->tb.set_standard(ctx, table));
-        p->table_copy.assign(table, table + GASM_TABLE_ROWS);
-        p->table_set = true;
-    }
-    GCHK(pipeline_build_finish_n(ctx, nullptr, p->n_local, p->bs, nullptr));
-    if (!p->paths_ready) {
-        GCHK(pipeline_contig_paths(ctx, p->own, p->bs, p->dp));
-        p->paths_ready = true;
-    }
-    pipeline_contig_paths_host(p->own, p->bs, p->dp);
-    return pipeline_score_launch(ctx, p->own, p->dp, kmer, p->tb, false, false, p->ss, &p->bs);
+    return pool_score_launch(p, kmer, table, true);
     POOL_GUARD_END
 }
 
@@ -358,7 +363,7 @@ int gasm_pool_fetch_distinct(gasm_pool* p, const uint64_t** seg_off, const uint6
     POOL_GUARD_BEGIN
     if (!p || !seg_off || !keys || !mult || !words) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (!p->graphed) { gasm_set_error("fetch before gasm_pool_graph"); return GASM_ERR_STATE; }
-    GCHK(pipeline_build_finish_n(p->ctx, nullptr, p->n_local, p->bs, nullptr));
+    GCHK(pool_finish(p));
     GCHK(pipeline_fetch_distinct(p->ctx, p->own, p->bs));
     *seg_off = p->bs.h_seg_doff.data(); *keys = p->bs.h_dk_key.data(); *mult = p->bs.h_dk_cnt.data(); *words = p->bs.words;
     return GASM_OK;
@@ -369,7 +374,7 @@ int gasm_pool_fetch_contigs(gasm_pool* p, const uint64_t** seg_contig_off, const
     POOL_GUARD_BEGIN
     if (!p || !seg_contig_off || !off || !data) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (!p->graphed) { gasm_set_error("fetch before gasm_pool_graph"); return GASM_ERR_STATE; }
-    GCHK(pipeline_build_finish_n(p->ctx, nullptr, p->n_local, p->bs, nullptr));
+    GCHK(pool_finish(p));
     GCHK(pipeline_fetch_contigs(p->ctx, p->own, p->bs));
     *seg_contig_off = p->bs.h_seg_coff.data(); *off = p->bs.h_c_off.data(); *data = p->bs.h_contigs.data();
     return GASM_OK;
@@ -380,7 +385,7 @@ int gasm_pool_fetch_scores(gasm_pool* p, const double** bp_score, const double**
                            const int32_t** kmer_breaks, const int32_t** sequence_len) {
     POOL_GUARD_BEGIN
     if (!p || !bp_score || !norm_by_break_freqs || !norm_by_len || !kmer_breaks || !sequence_len) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
-    GCHK(pipeline_build_finish_n(p->ctx, nullptr, p->n_local, p->bs, nullptr));
+    GCHK(pool_finish(p));
     GCHK(pipeline_score_fetch(p->ctx, p->ss));
     *bp_score = p->ss.h_bp.data(); *norm_by_break_freqs = p->ss.h_nf.data(); *norm_by_len = p->ss.h_nl.data();
     *kmer_breaks = p->ss.h_breaks.data(); *sequence_len = p->ss.h_len.data();

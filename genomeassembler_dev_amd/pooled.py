@@ -101,12 +101,10 @@ class GasmBackend:
     def __init__(self, reads, seg_read_off, fixed_len, ctx=None, device=None):
         import ctypes as C
 
-        import torch
-
         from ._lib import check, default_context, lib
-        self.C, self.torch, self.lib, self.check = C, torch, lib(), check
+        self.C, self.lib, self.check = C, lib(), check
         self.ctx = ctx or default_context()
-        self.device = torch.device("cuda", self.ctx.device) if device is None else device
+        self._device = device
         reads = np.ascontiguousarray(reads, dtype=np.uint8).reshape(-1)
         self.seg_read_off = np.ascontiguousarray(seg_read_off, dtype=np.uint64)
         self.n_segments = len(self.seg_read_off) - 1
@@ -117,6 +115,19 @@ class GasmBackend:
         self.h = h
         self.words = 1
         self.k = None
+
+    # torch is needed only by the stage-by-stage protocol below (exchange buffers as tensors); the library's own exchange
+    # (`exchange_build`) never touches it
+    @property
+    def torch(self):
+        import torch
+        return torch
+
+    @property
+    def device(self):
+        if self._device is None:
+            self._device = self.torch.device("cuda", self.ctx.device)
+        return self._device
 
     def _sync_torch(self):
         self.torch.cuda.current_stream(self.device).synchronize()
@@ -224,6 +235,92 @@ class GasmBackend:
         if self.h:
             self.lib.gasm_pool_free(self.h)
             self.h = None
+
+
+# ------------------------------------------------------------------------------------------------- the library's own exchange
+class Comm:
+    """A communicator of libgasm (include/gasm.h, csrc/exchange.hip): RCCL — one rank per process, created from a 128-byte id
+    that rank 0 makes (`Comm.unique_id()`) and the caller's bootstrap hands round — or `world` virtual ranks of this process
+    on one GPU (the exchanges are device copies: the same plans and kernels, testable on a one-GPU box)."""
+
+    def __init__(self, h, ctx, world, rank):
+        self.h, self.ctx, self.world, self.rank = h, ctx, world, rank
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+
+        from ._lib import check, lib
+        buf = C.create_string_buffer(128)
+        check(lib().gasm_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, ctx, uid, rank, world):
+        import ctypes as C
+
+        from ._lib import check, lib
+        h = C.c_void_p()
+        check(lib().gasm_comm_create(ctx.h, C.create_string_buffer(bytes(uid), 128), int(rank), int(world), C.byref(h)))
+        return cls(h, ctx, int(world), int(rank))
+
+    @classmethod
+    def virtual(cls, ctx, world):
+        import ctypes as C
+
+        from ._lib import check, lib
+        h = C.c_void_p()
+        check(lib().gasm_comm_create_virtual(ctx.h, int(world), C.byref(h)))
+        return cls(h, ctx, int(world), -1)
+
+    def stage(self):
+        from ._lib import lib
+        return lib().gasm_comm_stage(self.h)
+
+    def close(self):
+        from ._lib import lib
+        if self.h:
+            lib().gasm_comm_destroy(self.h)
+            self.h = None
+
+
+def owners(n_segments, bbits, world):
+    """(bucket owner per bucket, first segment of every rank) as libgasm computes them (gasm_pool_bucket_owner / _segment_bounds)"""
+    import ctypes as C
+
+    from ._lib import check, lib
+    own = np.zeros(n_segments << bbits, dtype=np.uint32)
+    first = np.zeros(world + 1, dtype=np.uint32)
+    check(lib().gasm_pool_bucket_owner(n_segments, bbits, world, own.ctypes.data_as(C.c_void_p)))
+    check(lib().gasm_pool_segment_bounds(n_segments, world, first.ctypes.data_as(C.c_void_p)))
+    return own, first
+
+
+def exchange_build(comm, backends, k, bbits, kmer=8, table=None):
+    """One pooled step through gasm_pool_exchange_build: `backends` = this rank's GasmBackend (RCCL) or the list of all virtual
+    ranks' backends in rank order.  Returns (stats dict, {rank: (first own segment, one past the last)}); per-segment results
+    are the backends' (`results()`)."""
+    import ctypes as C
+
+    from ._lib import check, lib
+    bl = list(backends) if isinstance(backends, (list, tuple)) else [backends]
+    arr = (C.c_void_p * len(bl))(*[b.h for b in bl])
+    st = (C.c_uint64 * 8)()
+    t = None
+    if table is not None:
+        t = np.ascontiguousarray(table, dtype=np.float64)
+    check(lib().gasm_pool_exchange_build(comm.h, arr, len(bl), int(k), int(bbits), int(kmer), t.ctypes.data_as(C.c_void_p) if t is not None else None, st))
+    n_segments = bl[0].n_segments
+    _own, first = owners(n_segments, int(st[7]), comm.world)
+    ranks = range(comm.world) if comm.rank < 0 else [comm.rank]
+    own = {}
+    for b, r in zip(bl, ranks):
+        b.k, b.bbits, b.n_local = int(k), int(st[7]), int(first[r + 1] - first[r])
+        b.words = lib().gasm_pool_key_words(b.h)
+        own[r] = (int(first[r]), int(first[r + 1]))
+    stats = {"bytes_sent": [int(st[0]), int(st[1]), int(st[2])], "bytes_sent_remote": [int(st[3]), int(st[4]), int(st[5])],
+             "attempts": int(st[6]), "bbits": int(st[7])}
+    return stats, own
 
 
 # ------------------------------------------------------------------------------------------------- the protocol

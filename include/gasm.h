@@ -286,6 +286,44 @@ int gasm_pool_fetch_scores(gasm_pool* p, const double** bp_score, const double**
                            const int32_t** kmer_breaks, const int32_t** sequence_len);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * The pooled step with the exchanges inside the library (csrc/exchange.hip): what the north star calls "an RCCL all-to-all
+ * over xGMI to bucket k-mers by hash before the global edge-list merge", as ONE call per step.  The reference analogue is
+ * the sequential loop over segments, scripts/02_Real_vs_rand_prob_own.R:33-53.
+ *
+ *   gasm_comm_unique_id          128 bytes (ncclUniqueId) made by one rank and handed to all others by the caller's
+ *                                bootstrap (a file, MPI, torch.distributed's store, ...): the only thing the host layer moves
+ *   gasm_comm_create             ncclCommInitRank on the context's GPU: one rank per process, RCCL over xGMI
+ *   gasm_comm_create_virtual     `world` ranks inside this process on one GPU; exchanges become device copies on the context's
+ *                                stream — the same plans, kernels and directories, testable on a one-GPU box
+ *   gasm_comm_stage              what the running gasm_pool_exchange_build is doing (10 local runs, 11/12/13 exchange 1: plan,
+ *                                transfer, merge, 21/22/23 exchange 2, 31 reads, 32 scoring, 0 idle): for watchdogs
+ *   gasm_pool_bucket_owner       owner rank of every bucket (index = segment << bbits | prefix)
+ *   gasm_pool_segment_bounds     first[r] .. first[r + 1]: the segments rank r builds, scores and returns
+ *   gasm_pool_exchange_build     local runs -> all-to-all #1 -> merge -> all-to-all #2 -> graph + contigs -> all-to-all #3
+ *                                (reads) -> scoring (table != NULL).  pools: the caller's pool (RCCL) or one pool per
+ *                                virtual rank, in rank order.  Run lengths, offsets and run directories stay on the device;
+ *                                the host waits for two small reports per step (per-peer totals: ncclSend / ncclRecv take their
+ *                                counts from the host).  Capacity failures are collective: every rank's overflow flag travels
+ *                                with the length tables, all ranks take the same step of the retry ladder (exact partition,
+ *                                larger tables, two more bucket bits) or return GASM_ERR_CAPACITY together.
+ *                                stats (optional, 8 words): bytes the first local rank sent in exchange 1, 2, 3; of those to
+ *                                other ranks; attempts; bucket bits used.  Results: gasm_pool_fetch_* of every pool.
+ * ---------------------------------------------------------------------------------------------------------------- */
+#define GASM_COMM_ID_BYTES 128
+typedef struct gasm_comm gasm_comm;
+int gasm_comm_unique_id(void* id /* GASM_COMM_ID_BYTES */);
+int gasm_comm_create(gasm_ctx* ctx, const void* id, int rank, int world, gasm_comm** out);
+int gasm_comm_create_virtual(gasm_ctx* ctx, int world, gasm_comm** out);
+void gasm_comm_destroy(gasm_comm* c);
+int gasm_comm_world(const gasm_comm* c);
+int gasm_comm_rank(const gasm_comm* c);      /* -1: virtual */
+int gasm_comm_stage(const gasm_comm* c);
+int gasm_pool_bucket_owner(uint32_t n_segments, int bbits, uint32_t world, uint32_t* owner /* n_segments << bbits */);
+int gasm_pool_segment_bounds(uint32_t n_segments, uint32_t world, uint32_t* first /* world + 1 */);
+int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_pools, int k, int bbits, int kmer,
+                             const double* table /* 69 904 rows or NULL */, uint64_t* stats /* 8 words or NULL */);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Breakage-score-guided traversal (BASELINE configs[4]'s "combined" mode).  NOT in the reference
  * (README.md:83 "out of scope"): specified by this project, parity = agreement with the project's own CPU
  * restatement (oracle/guided_oracle.py).  Contigs end at branching nodes; guided scaffolds chain them through those nodes:

@@ -166,3 +166,31 @@ def test_get_kmers_from_reads_matches_oracle():
     reads = ["ACGTACGTAC", "TTTT", "ACG", "GATTACAGATTACA"]
     for k in (3, 4, 5):
         assert ga.get_kmers_from_reads(reads, k) == orc.kmers_from_reads(reads, k)
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """libgasm and PyTorch must share ONE copy of the HIP runtime, whichever is loaded first (round 2 lost a GPU test run to
+    "No HIP GPUs are available": libgasm had mapped ROCm's copy, torch then brought its own)."""
+    import subprocess
+    import sys
+    code_a = ("from genomeassembler_dev_amd import _lib; _lib.lib(); import torch; torch.cuda.is_available(); "
+              "print(len(_lib.hip_runtimes_mapped()))")
+    code_b = ("import torch; from genomeassembler_dev_amd import _lib; _lib.lib(); torch.cuda.is_available(); "
+              "print(len(_lib.hip_runtimes_mapped()))")
+    for code in (code_a, code_b):
+        out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
+
+
+def test_ownership_functions_c_and_python_agree():
+    """gasm_pool_bucket_owner / gasm_pool_segment_bounds (what the library's exchange plans with) against pooled.py's numpy
+    forms (what the gloo tests run)."""
+    import numpy as np
+
+    from genomeassembler_dev_amd import pooled
+    from genomeassembler_dev_amd.parallel import shard_bounds
+    for n_seg, bbits, world in ((1, 0, 1), (7, 3, 2), (100, 6, 8), (1000, 6, 8), (13, 10, 5), (3, 2, 7)):
+        own, first = pooled.owners(n_seg, bbits, world)
+        assert own.tolist() == pooled.bucket_owner(n_seg, bbits, world).tolist(), (n_seg, bbits, world)
+        assert first.tolist() == [a for a, _ in shard_bounds(n_seg, world)] + [n_seg], (n_seg, bbits, world)
