@@ -233,6 +233,16 @@ static int x_alltoallv(gasm_comm* c, const XStream* st, int n_streams, const std
     return GASM_OK;
 }
 
+// GASM_X_SYNC=1 (diagnostic): wait for the stream after every stage and say which stage it was
+static int stage_done(gasm_comm* c, int stage) {
+    static const bool on = getenv("GASM_X_SYNC") != nullptr;
+    if (!on) return GASM_OK;
+    const hipError_t e = hipStreamSynchronize(c->ctx->stream);
+    fprintf(stderr, "[gasm exchange] stage %d done: %s\n", stage, hipGetErrorString(e));
+    if (e != hipSuccess) { gasm_set_error("stage %d failed: %s", stage, hipGetErrorString(e)); return GASM_ERR_HIP; }
+    return GASM_OK;
+}
+
 // ---- the ownership plan of (S, bbits) on the device
 static int comm_plan(gasm_comm* c, u32 S, int bbits) {
     if (c->S == S && c->bbits == bbits) return GASM_OK;
@@ -563,6 +573,7 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
         c->stage = 10;
         for (u32 li = 0; li < nl; ++li) GCHK(local_runs_queue(pools[li], c->rx[li], k, bbits, small_tbl, single_pass));
         // ---- stage 11: lengths + flags of everybody, plan 1, report 1
+        GCHK(stage_done(c, 10));
         c->stage = 11;
         for (u32 li = 0; li < nl; ++li) {
             RankX& x = c->rx[li];
@@ -600,6 +611,7 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
             continue;
         }
         // ---- stage 12: all-to-all #1
+        GCHK(stage_done(c, 11));
         c->stage = 12;
         std::vector<std::vector<u64>> soff(nl, std::vector<u64>(W + 1, 0)), roff(nl, std::vector<u64>(W + 1, 0));
         std::vector<const void*> sk(nl), sc(nl);
@@ -621,6 +633,7 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
             GCHK(x_alltoallv(c, st, 2, soff, roff, &st_bytes[0], &st_remote[0]));
         }
         // ---- stage 13: merge
+        GCHK(stage_done(c, 12));
         c->stage = 13;
         for (u32 li = 0; li < nl; ++li) {
             RankX& x = c->rx[li];
@@ -628,6 +641,7 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
             GCHK(merge_received(pools[li], x, n_mine, W, x.rep[2 * W], x.rep + W));
         }
         // ---- stage 21: merged lengths + flags of everybody, plan 2, report 2
+        GCHK(stage_done(c, 13));
         c->stage = 21;
         for (u32 li = 0; li < nl; ++li) {
             RankX& x = c->rx[li];
@@ -645,6 +659,7 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
             RankX& x = c->rx[li];
             const u32 r = c->global_rank(li), n_mine = (u32)c->h_mine[r].size();
             const u32 a = c->h_seg_first[r], b = c->h_seg_first[r + 1];
+            GCHK(x.d_bstart_new.ensure(((size_t)std::max(n_mine, nbt) + 2) * 8));     // (the merge took the last one for the pool's runs)
             HIPCHK(hipMemcpyAsync(x.d_flags_or.p, x.d_G.as<u32>() + nbt, 4, hipMemcpyDeviceToDevice, ctx->stream));
             GLAUNCH(ctx, "k_x2_plan", k_x2_plan, dim3(W + 2), dim3(1024), 0, x.d_G.as<u32>(), c->d_own1.as<u16>(), W, r, a * nb, (b - a) * nb, bbits, x.d_mine.as<u32>(), n_mine,
                     c->d_seg_first.as<u32>(), x.d_send_off.as<u64>(), x.d_send_tot.as<u64>(), x.d_run_off.as<u64>(), x.d_run_len.as<u32>(), x.d_recv_tot.as<u64>(),
@@ -664,6 +679,7 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
             return GASM_ERR_CAPACITY;
         }
         // ---- stage 22: all-to-all #2
+        GCHK(stage_done(c, 21));
         c->stage = 22;
         for (u32 li = 0; li < nl; ++li) {
             RankX& x = c->rx[li];
@@ -684,6 +700,7 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
             GCHK(x_alltoallv(c, st, 2, soff, roff, &st_bytes[1], &st_remote[1]));
         }
         // ---- stage 23: placement, graph, contigs of the rank's own segments
+        GCHK(stage_done(c, 22));
         c->stage = 23;
         for (u32 li = 0; li < nl; ++li) {
             RankX& x = c->rx[li];
@@ -696,6 +713,7 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
     }
     // ---- stage 31: the reads of a segment to the segment's owner
     if (table) {
+        GCHK(stage_done(c, 23));
         c->stage = 31;
         bool first = false;
         for (u32 li = 0; li < nl; ++li) first = first || !(c->rx[li].reads_ready && c->rx[li].reads_id == pools[li]->rd.upload_id);
@@ -720,9 +738,11 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
             if (d != c->global_rank(0)) st_remote[2] += n * 8;
         }
         // ---- stage 32: scoring, queued behind the graph
+        GCHK(stage_done(c, 31));
         c->stage = 32;
         for (u32 li = 0; li < nl; ++li) GCHK(pool_score_launch(pools[li], kmer, table, false));
     }
+    GCHK(stage_done(c, 32));
     c->stage = 0;
     if (stats) {
         for (int i = 0; i < 3; ++i) { stats[i] = st_bytes[i]; stats[3 + i] = st_remote[i]; }
