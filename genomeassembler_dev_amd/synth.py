@@ -52,3 +52,17 @@ def make_batch(n_segments, seg_len, read_len, coverage, seed0=1234, planted=True
         reads.append(r)
         off.append(off[-1] + r.shape[0])
     return np.concatenate(reads, axis=0), np.array(off, dtype=np.uint64), genomes
+
+
+def pack_2bit(ascii_bases):
+    """ASCII ACGT (uint8, any shape, read after read) -> uint64 words, 32 bases per word, first base most significant
+    (A=0 C=1 G=2 T=3): the layout gasm_batch_create_packed takes — a quarter of the bytes over PCIe"""
+    a = np.ascontiguousarray(ascii_bases, dtype=np.uint8).reshape(-1)
+    code = ((a >> 1) & 3) ^ ((a >> 2) & 1)
+    n = code.size
+    pad = (-n) % 32
+    if pad:
+        code = np.concatenate([code, np.zeros(pad, dtype=np.uint8)])
+    c = code.reshape(-1, 32).astype(np.uint64)
+    shifts = (62 - 2 * np.arange(32, dtype=np.uint64)).astype(np.uint64)
+    return np.bitwise_or.reduce(c << shifts[None, :], axis=1)

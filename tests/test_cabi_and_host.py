@@ -194,3 +194,22 @@ def test_ownership_functions_c_and_python_agree():
         own, first = pooled.owners(n_seg, bbits, world)
         assert own.tolist() == pooled.bucket_owner(n_seg, bbits, world).tolist(), (n_seg, bbits, world)
         assert first.tolist() == [a for a, _ in shard_bounds(n_seg, world)] + [n_seg], (n_seg, bbits, world)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks under torch.distributed.run before anything touches
+    a GPU; without GPUs the ranks then fail at "no GPU" — and the parent reports the failure with a non-zero status."""
+    import subprocess
+    import sys
+
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the driver's own runs cover this")
+    env = dict(os.environ)
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "starting 2 ranks" in p.stderr
+    assert p.stderr.count("No HIP GPUs are available") + p.stderr.count("GASM_ERR_NO_DEVICE") >= 1, p.stderr[-3000:]
+    assert "rank      : 1" in p.stderr or "local_rank: 1" in p.stderr       # the second rank existed
