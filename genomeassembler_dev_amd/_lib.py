@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgasm.so")
+LIB_PATH = os.environ.get("GASM_LIBGASM") or os.path.join(_HERE, "libgasm.so")     # (GASM_LIBGASM: a build variant, experiments only)
 
 GASM_OK = 0
 STATUS = {0: "GASM_OK", -1: "GASM_ERR_INVALID", -2: "GASM_ERR_NON_ACGT", -3: "GASM_ERR_NO_DEVICE", -4: "GASM_ERR_HIP",

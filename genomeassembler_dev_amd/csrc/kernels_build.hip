@@ -28,6 +28,24 @@
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
+// The key array is written once (partition) and read once (de-duplication): 1.6 GB per step that nothing reads twice.
+// GASM_NT_LOADS / GASM_NT_STORES (compile time) mark those accesses non-temporal; measured in NOTES_r3.md.
+typedef unsigned int u32x4nt __attribute__((ext_vector_type(4)));
+#ifdef GASM_NT_LOADS
+__device__ __forceinline__ uint4 stream_load16(const uint4* p) {
+    const u32x4nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4nt*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+#define GASM_STREAM_LOAD(p) stream_load16(p)
+#else
+#define GASM_STREAM_LOAD(p) (*(p))
+#endif
+#ifdef GASM_NT_STORES
+#define GASM_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define GASM_STREAM_STORE(v, p) (*(p) = (v))
+#endif
+
 // ================================================================================================================
 // ASCII -> 2-bit.  One thread per output word (32 bases) and grid-stride round; 2 x 16-byte loads where the word is fully
 // inside.  nbases_dev (optional): the number of bases lives on the device (the contigs of a build the host has not
@@ -561,7 +579,7 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 4) k_bucket_partition(ReadSet rs
 #pragma unroll
             for (u32 u = 0; u < 3; ++u) {
                 const u32 i = (t + GASM_TILE_WG * (u0 + u)) * KPU;
-                *reinterpret_cast<u64x2*>(keys + ((i < total && cb[u] != ~0ull) ? cb[u] + i : my_scratch)) = wd[u];
+                GASM_STREAM_STORE(wd[u], reinterpret_cast<u64x2*>(keys + ((i < total && cb[u] != ~0ull) ? cb[u] + i : my_scratch)));
             }
         }
         if (++tile >= tile_end) break;
@@ -734,7 +752,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     uint4 v[NLD];
     auto fetch = [&](u64 c) {
 #pragma unroll
-        for (int q = 0; q < NLD; ++q) v[q] = c + (u64)q * GASM_WG < nch ? src[c + (u64)q * GASM_WG] : make_uint4(~0u, ~0u, ~0u, ~0u);
+        for (int q = 0; q < NLD; ++q) v[q] = c + (u64)q * GASM_WG < nch ? GASM_STREAM_LOAD(&src[c + (u64)q * GASM_WG]) : make_uint4(~0u, ~0u, ~0u, ~0u);
     };
     if (threadIdx.x < nch) fetch(threadIdx.x);
     for (u64 c = threadIdx.x; c < nch; c += NLD * GASM_WG) {
