@@ -28,21 +28,22 @@
 
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 
-// The key array is written once (partition) and read once (de-duplication): 1.6 GB per step that nothing reads twice.
-// GASM_NT_LOADS / GASM_NT_STORES (compile time) mark those accesses non-temporal; measured in NOTES_r3.md.
+// The key array is written once (partition) and read once (de-duplication): 1.6 GB per step that nothing touches twice.  Both
+// accesses are marked non-temporal (`nt`).  Measured on MI355X, cfg2, same box back to back (NOTES_r3.md): plain 1.168 ms/step
+// (de-duplication 0.455 ms); nt loads 1.103 (0.393); nt stores 1.113 (0.401 — the stores are the partition's, the gain is the
+// de-duplication's: it no longer reads through dirty lines the previous kernel left in L2 / Infinity Cache); both 1.081 (0.378).
+// Other policies on the stores (sc1, sc0 sc1, sc1 nt, sc0 sc1 nt, sc0 nt, inline asm) were all slower than plain nt.
+// GASM_NO_NT (compile time) restores plain accesses.
 typedef unsigned int u32x4nt __attribute__((ext_vector_type(4)));
-#ifdef GASM_NT_LOADS
+#ifndef GASM_NO_NT
 __device__ __forceinline__ uint4 stream_load16(const uint4* p) {
     const u32x4nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4nt*>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 #define GASM_STREAM_LOAD(p) stream_load16(p)
-#else
-#define GASM_STREAM_LOAD(p) (*(p))
-#endif
-#ifdef GASM_NT_STORES
 #define GASM_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #else
+#define GASM_STREAM_LOAD(p) (*(p))
 #define GASM_STREAM_STORE(v, p) (*(p) = (v))
 #endif
 
@@ -426,7 +427,7 @@ __global__ void __launch_bounds__(GASM_TILE_WG, 1024 / GASM_TILE_WG) k_bucket_sc
 #pragma unroll
             for (u32 u = 0; u < 3; ++u) {
                 const u32 i = (tid + GASM_TILE_WG * (u0 + u)) * KPU;
-                *reinterpret_cast<u64x2*>(keys + (i < total ? cb[u] + i : my_scratch)) = w[u];   // (no branch: the number of stores must not vary)
+                GASM_STREAM_STORE(w[u], reinterpret_cast<u64x2*>(keys + (i < total ? cb[u] + i : my_scratch)));   // (no branch: the number of stores must not vary)
             }
         }
         if (++tile >= tile_end) break;
