@@ -48,6 +48,7 @@ SYMBOLS = {
     "gasm_assemble_contigs_velvet_dev": (_int, [_vp, _vp, _vp, _u64, _int, _int, _int, _PP]),
     "gasm_scaffolds_count": (_u64, [_vp]),
     "gasm_scaffolds_offsets": (_vp, [_vp]),
+    "gasm_scaffolds_merge_device": (_int, [_vp, C.POINTER(_u64)]),
     "gasm_scaffolds_fetch": (_int, [_vp, _PP]),
     "gasm_scaffolds_free": (None, [_vp]),
     "gasm_calc_breakscore_dev": (_int, [_vp, _vp, _vp, _vp, _u64, _vp, _u64, _int, _vp, _vp, _u64, _vp, _int, _int, _PP]),
@@ -69,6 +70,7 @@ SYMBOLS = {
     "gasm_scores_prob_dist": (_vp, [_vp]),
     "gasm_scores_prob_dist_offsets": (_vp, [_vp]),
     "gasm_scores_ks": (_vp, [_vp]),
+    "gasm_scores_lev_device": (_int, [_vp]),
     "gasm_coverage_percent": (_int, [_vp, _vp, _vp, _u64, C.c_int64, _vp]),
     "gasm_scores_free": (None, [_vp]),
     "gasm_levenshtein": (_int, [_vp, _u64, _vp, _u64, _int, C.POINTER(_i32)]),

@@ -141,6 +141,9 @@ class Scaffolds:
         n = lib().gasm_scaffolds_count(h)
         off = _arr(lib().gasm_scaffolds_offsets(h), C.c_uint64, n + 1)
         self.lengths = np.diff(off).astype(np.int64) if n else np.zeros(0, np.int64)
+        r = C.c_uint64()
+        self.merge_device = {0: None, 1: "gpu", 2: "host", 3: "gpu+host"}[lib().gasm_scaffolds_merge_device(h, C.byref(r))]
+        self.rows_on_host = int(r.value)
 
     def __len__(self):
         return len(self.lengths)
@@ -258,6 +261,7 @@ def calc_breakscore(path, sequencing_reads, true_solution, kmer, bp_kmer, bp_pro
             out["path_freq"] = f.reshape(n, len(bp_kmer))
         if with_ks:
             out["stat_test_KS"] = _arr(L.gasm_scores_ks(h), C.c_double, n)
+        out["lev_device"] = {0: None, 1: "gpu", 2: "host"}[L.gasm_scores_lev_device(h)]      # (not a reference column: who did the work)
     finally:
         L.gasm_scores_free(h)
     return out

@@ -36,6 +36,7 @@ struct gasm_scores {
     std::vector<double> bp, nf, nl, freq, pd, ks;
     std::vector<u64> pd_off;
     bool has_freq = false, velvet = false, has_ks = false;
+    int lev_device = 0;      // who computed lev: 0 nobody (not asked), 1 the GPU (k_levenshtein), 2 host threads (gasm_host::levenshtein)
 };
 
 // A batch runs as one or more sub-batches — contiguous blocks of its segments, each with its own reads, build and
@@ -186,10 +187,15 @@ static int assemble_device(gasm_ctx* ctx, const char* contigs, const u64* off, u
     std::vector<std::string> sigs;
     bool on_gpu = false;
     // the merge itself on the GPU (a wave per permutation); GASM_ASM_HOST_MERGE=1: on host threads (same signatures)
-    if (!getenv("GASM_ASM_HOST_MERGE")) GCHK(assemble_signatures_device(ctx, c, perm, rows, row_len, k, sigs, &on_gpu, nullptr));
+    u64 rows_on_host = 0;
+    if (!getenv("GASM_ASM_HOST_MERGE")) GCHK(assemble_signatures_device(ctx, c, perm, rows, row_len, k, sigs, &on_gpu, &rows_on_host));
     if (!on_gpu && !gasm_host::assemble_signatures(c, perm, rows, row_len, k, sigs)) return GASM_OK;
     *used = true;
-    return scaffolds_from_signatures(ctx, c, sigs, out);
+    GCHK(scaffolds_from_signatures(ctx, c, sigs, out));
+    // who ran the greedy merge (the results are the same; a caller can ask): the GPU, host threads, or both
+    (*out)->rows_total = rows;
+    (*out)->rows_on_host = on_gpu ? rows_on_host : rows;
+    return GASM_OK;
 }
 
 static int assemble_common(gasm_ctx* ctx, const char* contigs, const u64* off, u64 n, const u32* perm, u64 rows, u64 row_len, int k, gasm_strlist** out) {
@@ -283,6 +289,11 @@ int gasm_assemble_contigs_velvet_dev(gasm_ctx* ctx, const char* contigs, const u
 }
 
 uint64_t gasm_scaffolds_count(const gasm_scaffolds* s) { return s ? s->n : 0; }
+int gasm_scaffolds_merge_device(const gasm_scaffolds* s, uint64_t* rows_on_host) {
+    if (rows_on_host) *rows_on_host = s ? s->rows_on_host : 0;
+    if (!s) return 0;
+    return s->rows_on_host == 0 ? 1 : (s->rows_on_host >= s->rows_total ? 2 : 3);
+}
 const uint64_t* gasm_scaffolds_offsets(const gasm_scaffolds* s) { return s ? s->h_off.data() : nullptr; }
 int gasm_scaffolds_fetch(const gasm_scaffolds* s, gasm_strlist** out) {
     API_GUARD_BEGIN
@@ -409,9 +420,11 @@ static int breakscore_impl(gasm_ctx* ctx, DevPaths& dp, const std::function<std:
         if (st == GASM_OK && (flags & GASM_WANT_LEV) && lev_gpu) {
             // lib/DeNovoAssembler.cpp:463 (global) / lib/BreakageScorer.cpp:339 (infix): one wave per path on the GPU
             st = pipeline_levenshtein(ctx, dp, true_solution, true_len, velvet, s->lev, &lev_done);
+            if (lev_done) s->lev_device = 1;
         }
         if (st == GASM_OK && (flags & GASM_WANT_LEV) && !lev_done) {
             // target with bytes outside ACGT (or GASM_LEV_HOST set): the host routine, threads over paths
+            s->lev_device = 2;
             std::atomic<u64> next(0);
             unsigned nt = std::thread::hardware_concurrency();
             nt = std::max(1u, std::min(nt, 32u));
@@ -473,6 +486,7 @@ const int32_t* gasm_scores_startpos(const gasm_scores* s) { return s && s->velve
 const double* gasm_scores_prob_dist(const gasm_scores* s) { return s && s->velvet ? s->pd.data() : nullptr; }
 const uint64_t* gasm_scores_prob_dist_offsets(const gasm_scores* s) { return s && s->velvet ? s->pd_off.data() : nullptr; }
 const double* gasm_scores_ks(const gasm_scores* s) { return s && s->has_ks ? s->ks.data() : nullptr; }
+int gasm_scores_lev_device(const gasm_scores* s) { return s ? s->lev_device : 0; }
 
 int gasm_coverage_percent(gasm_ctx* ctx, const int64_t* start, const int64_t* len, uint64_t n, int64_t seq_len, double* percent) {
     API_GUARD_BEGIN

@@ -1,6 +1,8 @@
 // ctx.cpp — context, error text, per-kernel HIP-event profiling.
 #include "gasm_internal.h"
 
+#include <dlfcn.h>
+
 static thread_local std::string g_err;
 
 void gasm_set_error(const char* fmt, ...) {
@@ -11,6 +13,30 @@ void gasm_set_error(const char* fmt, ...) {
     va_end(ap);
     g_err = buf;
 }
+
+// roctx ranges around the stages (the reference brackets its phases with Sys.time()): rocprofv3 --marker-trace shows
+// them.  libroctx64 is resolved at first use; without it (or with GASM_ROCTX=0) the calls are no-ops.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* off = getenv("GASM_ROCTX");
+        if (off && *off == '0') return;
+        for (const char* n : {"libroctx64.so.4", "libroctx64.so", "/opt/rocm/lib/libroctx64.so.4"}) {
+            if (void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+}  // namespace
+void gasm_range_push(const char* name) { if (roctx().push) roctx().push(name); }
+void gasm_range_pop() { if (roctx().pop) roctx().pop(); }
 
 extern "C" const char* gasm_last_error(void) { return g_err.c_str(); }
 extern "C" const char* gasm_version(void) { return "libgasm 0.1 (gfx950)"; }

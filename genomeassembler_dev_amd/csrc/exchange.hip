@@ -551,6 +551,7 @@ int gasm_pool_exchange_build(gasm_comm* c, gasm_pool* const* pools, uint32_t n_p
         if (pools[li]->rd.n_segments != pools[0]->rd.n_segments || pools[li]->rd.fixed_len != pools[0]->rd.fixed_len) { gasm_set_error("the pools disagree on segments or read length"); return GASM_ERR_INVALID; }
     }
     HIPCHK(hipSetDevice(ctx->device));
+    GasmRange range("gasm:pool exchange + build");
     const u32 S = pools[0]->rd.n_segments;
     u64 st_bytes[3] = {0, 0, 0}, st_remote[3] = {0, 0, 0};
     int attempts = 0;

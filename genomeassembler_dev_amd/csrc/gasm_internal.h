@@ -19,6 +19,13 @@ typedef uint16_t u16;
 typedef uint8_t u8;
 
 void gasm_set_error(const char* fmt, ...);
+// roctx range around a stage (ctx.cpp); GasmRange: the same as a scope
+void gasm_range_push(const char* name);
+void gasm_range_pop();
+struct GasmRange {
+    explicit GasmRange(const char* name) { gasm_range_push(name); }
+    ~GasmRange() { gasm_range_pop(); }
+};
 
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \

@@ -14,6 +14,7 @@ struct DevReads {
     std::vector<u64> h_seg_read_off;        // n_segments+1
     std::vector<u64> h_seg_empty;           // empty reads per segment
     bool positioned = false;                // fixed-length reads at the base positions in d_read_off (pooled builds)
+    int sim_shift = 52;                     // fixed-point shift of the last weighted simulate()
     u64 upload_id = 0;                      // changes with every upload: "the same reads again?" (BuildState)
     DBuf d_words, d_read_off, d_seg_read_off;
     // tile directory cache (depends on reads per tile)

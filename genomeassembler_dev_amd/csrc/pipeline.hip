@@ -253,11 +253,25 @@ int DevReads::simulate(gasm_ctx* ctx, const char* genomes, const u64* genome_off
     if (table) {
         // the kmer-long rows of the standard table (rows of lengths 2, 4, 6, 8 in that order), direct-addressed, in fixed point
         if (kmer != 2 && kmer != 4 && kmer != 6 && kmer != 8) { gasm_set_error("the weighted simulator needs kmer in {2,4,6,8} (the table's row lengths)"); return GASM_ERR_INVALID; }
+        // fixed-point weights round(p * 2^shift), running sums in 64 bits: shift = 52 unless a segment's sum could then pass
+        // 2^62 (kmer = 2 on a genome of more than ~65 kb: the sum used to wrap and k_sim_draw bisected a non-monotone CDF) —
+        // then the largest shift that cannot.  The oracle takes the same shift (sim_weight_shift, oracle/orc.py)
         std::vector<long long> fx(87380, 0);
+        double max_p = 0;
+        {
+            u32 src = 0;
+            for (u32 Lk = 2; Lk <= 8; Lk += 2) {
+                const u32 n = 1u << (2 * Lk);
+                for (u32 v = 0; v < n; ++v, ++src) if ((int)Lk == kmer) max_p = std::max(max_p, table[src]);
+            }
+        }
+        int shift = 52;
+        while (shift > 0 && std::ldexp(max_p, shift) * (double)std::max<u64>(max_np, 1) >= 4611686018427387904.0) --shift;
+        sim_shift = shift;
         u32 src = 0;
         for (u32 Lk = 2; Lk <= 8; Lk += 2) {
             const u32 n = 1u << (2 * Lk), b = ((1u << (2 * Lk)) - 4u) / 3u;
-            for (u32 v = 0; v < n; ++v, ++src) if ((int)Lk == kmer) fx[b + v] = std::llrint(std::ldexp(table[src], 52));
+            for (u32 v = 0; v < n; ++v, ++src) if ((int)Lk == kmer) fx[b + v] = std::llrint(std::ldexp(table[src], shift));
         }
         GCHK(h2d(ctx, d_fix, fx.data(), fx.size() * 8));
         fixw = d_fix.as<long long>();
@@ -465,6 +479,7 @@ static GraphView graph_view(const BuildState& bs) {
 
 // ---- reads -> per-(segment, bucket) distinct k-mers with multiplicities (in place in d_keys / d_mult) + dstart
 int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
+    GasmRange range("gasm:distinct (partition + de-duplication)");
     const int k = bs.k, W = bs.words, bbits = bs.bbits;
     const size_t KB = 8 * (size_t)W;
     const u32 S = rd.n_segments, nb = 1u << bbits, nbt = S * nb;
@@ -651,6 +666,7 @@ int launch_graph(gasm_ctx* ctx, u32 S, BuildState& bs) {
 }
 
 static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
+    GasmRange range("gasm:graph (degrees, list ranking, contigs)");
     const int W = bs.words;
     u32* const d_claim = bs.d_nxt.as<u32>();
     u32* const d_seg_ncontig = reinterpret_cast<u32*>(bs.d_seg_cbases.as<u64>() + S);
@@ -666,7 +682,7 @@ static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
     if (W == 1) GLAUNCH(ctx, "k_edge_target", k_edge_target<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim);
     else GLAUNCH(ctx, "k_edge_target", k_edge_target<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_tgt, d_claim);
     GLAUNCH(ctx, "k_edge_multi", k_edge_multi, grid_grp, dim3(GASM_WG), 0, gv, S, gchunks, d_tgt, d_claim, bs.d_eflag.as<u8>());
-    // (k_node_flags also initialises link = none and clen = 0 for its edge)
+    // (links: k_edge_next is their only writer — every edge's — before the ranking reads them; chain lengths: k_link_jump / k_chain_len)
     if (W == 1) GLAUNCH(ctx, "k_node_flags", k_node_flags<u64>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_claim, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
     else GLAUNCH(ctx, "k_node_flags", k_node_flags<K128>, grid_seg, dim3(GASM_WG), 0, gv, S, dchunks, d_claim, bs.d_eflag.as<u8>(), bs.d_link.as<u64>(), bs.d_clen.as<u32>());
     GLAUNCH(ctx, "k_edge_next", k_edge_next, grid_grp, dim3(GASM_WG), 0, gv, S, gchunks, d_tgt, bs.d_eflag.as<u8>(), bs.d_nxt.as<u32>(), bs.d_link.as<u64>());
@@ -1035,6 +1051,7 @@ int ScoreTable::set_fixed(gasm_ctx* ctx, u64 max_terms) {
 // Levenshtein distances
 // ---------------------------------------------------------------------------------------------------------------
 int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 target_len, bool infix, std::vector<int32_t>& lev, bool* done) {
+    GasmRange range("gasm:levenshtein");
     *done = false;
     const u32 P = dp.n_paths;
     lev.assign(P, 0);
@@ -1144,6 +1161,7 @@ int pipeline_coverage(gasm_ctx* ctx, const long long* start, const long long* le
 // Batch scoring of a build's own contigs (gasm_batch_score): queued behind the build without waiting for it.  The number
 // of paths is read on the device (graph.d_seg_cstart[S]); outputs are allocated at the build's upper bound.
 static int score_launch_graph(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, const ScoreTable& tb, ScoreState& ss, const BuildState& graph) {
+    GasmRange range("gasm:score (graph-indexed)");
     const u32 S = rd.n_segments;
     const size_t PC = (size_t)graph.D_cap + 1;
     ss.stride = PC;
@@ -1208,6 +1226,7 @@ int pipeline_score_launch(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kmer, c
     if (kmer < 0) { gasm_set_error("kmer must be >= 0"); return GASM_ERR_INVALID; }
     if (rd.n_segments != dp.n_segments) { gasm_set_error("reads and paths disagree on the number of segments"); return GASM_ERR_INVALID; }
     HIPCHK(hipSetDevice(ctx->device));
+    GasmRange range("gasm:score");
     ss.valid = false;
     ss.n_table = tb.n_table;
     ss.want_freq = want_freq && tb.n_table;

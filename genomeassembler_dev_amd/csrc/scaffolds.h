@@ -7,6 +7,7 @@ struct gasm_scaffolds {
     DBuf d_words;               // 2-bit, scaffold after scaffold without gaps, + 4 padding words
     std::vector<u64> h_off;     // n + 1 base offsets, final (reference) order: longest first
     u32 n = 0;
+    u64 rows_total = 0, rows_on_host = 0;   // permutations merged in all / by the host routine (k_asm_merge hands back rows it cannot decide)
 };
 
 int scaffolds_from_signatures(gasm_ctx* ctx, const std::vector<std::string>& contigs, const std::vector<std::string>& sigs, gasm_scaffolds** out);

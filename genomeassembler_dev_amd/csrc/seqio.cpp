@@ -16,6 +16,8 @@ struct LineReader {
     gzFile f = nullptr;
     std::vector<char> buf;
     size_t pos = 0, end = 0;
+    bool failed = false;          // a read error or a truncated / corrupt gzip stream: the reads so far are NOT the file's reads
+    std::string fail_text;
     bool open(const char* path) {
         f = gzopen(path, "rb");
         if (!f) return false;
@@ -31,7 +33,20 @@ struct LineReader {
         for (;;) {
             if (pos == end) {
                 const int n = gzread(f, buf.data(), (unsigned)buf.size());
-                if (n <= 0) break;
+                if (n < 0 || (n == 0 && !gzeof(f))) {       // (n == 0 at a clean end of file; anything else is an error)
+                    int code = 0;
+                    const char* msg = gzerror(f, &code);
+                    failed = true;
+                    fail_text = msg && *msg ? msg : "read error";
+                    break;
+                }
+                if (n == 0) {
+                    // zlib reports a gzip stream that stops short of its trailer through gzerror (Z_BUF_ERROR), not through gzread
+                    int code = 0;
+                    const char* msg = gzerror(f, &code);
+                    if (code != Z_OK && code != Z_STREAM_END) { failed = true; fail_text = msg && *msg ? msg : "truncated stream"; }
+                    break;
+                }
                 pos = 0; end = (size_t)n;
             }
             any = true;
@@ -88,8 +103,12 @@ int read_sequence_file(const char* path, bool error_on_non_acgt, PackedReads& ou
         ++*n_kept;
         return GASM_OK;
     };
-    if (!lr.line(ln)) return GASM_OK;                       // empty file: no reads
-    while (ln.empty()) if (!lr.line(ln)) return GASM_OK;
+    auto eof_status = [&]() -> int {
+        if (lr.failed) { gasm_set_error("%s: %s (truncated or corrupt file)", path, lr.fail_text.c_str()); return GASM_ERR_INVALID; }
+        return GASM_OK;
+    };
+    if (!lr.line(ln)) return eof_status();                  // empty file: no reads
+    while (ln.empty()) if (!lr.line(ln)) return eof_status();
     if (ln[0] == '@') {
         u64 rec = 0;
         for (;;) {
@@ -127,6 +146,7 @@ int read_sequence_file(const char* path, bool error_on_non_acgt, PackedReads& ou
         gasm_set_error("%s: neither FASTQ ('@') nor FASTA ('>')", path);
         return GASM_ERR_INVALID;
     }
+    if (lr.failed) { gasm_set_error("%s: %s (truncated or corrupt file: its reads are not used)", path, lr.fail_text.c_str()); return GASM_ERR_INVALID; }
     return GASM_OK;
 }
 

@@ -105,6 +105,9 @@ int gasm_assemble_contigs_dev(gasm_ctx* ctx, const char* contigs, const uint64_t
 int gasm_assemble_contigs_velvet_dev(gasm_ctx* ctx, const char* contigs, const uint64_t* off, uint64_t n, int dbg_kmer, int seed,
                                      int rows, gasm_scaffolds** out);
 uint64_t gasm_scaffolds_count(const gasm_scaffolds* s);
+/* who ran the greedy merge behind these scaffolds: 1 the GPU (k_asm_merge), 2 host threads, 3 both (*rows_on_host of the
+ * permutations went back to the host routine: two chains of equal length need the reference's full-string test) */
+int gasm_scaffolds_merge_device(const gasm_scaffolds* s, uint64_t* rows_on_host);
 const uint64_t* gasm_scaffolds_offsets(const gasm_scaffolds* s);   /* count + 1 base offsets: lengths without a fetch */
 int gasm_scaffolds_fetch(const gasm_scaffolds* s, gasm_strlist** out);
 void gasm_scaffolds_free(gasm_scaffolds* s);
@@ -156,6 +159,9 @@ const uint64_t* gasm_scores_prob_dist_offsets(const gasm_scores* s);/* count+1 *
  * the true solution's kmer-long windows (kmer_from_seq, lib/GenerateReads.R:243-259): what ks.test(...)$statistic gives in
  * lib/DeNovoAssembler.R:419-424; NaN where no read matched (R stops with an error there).  NULL without GASM_WANT_KS. */
 const double* gasm_scores_ks(const gasm_scores* s);
+/* who computed lev_dist_vs_true: 0 nobody (not asked for), 1 the GPU (k_levenshtein), 2 host threads (a cost model prefers them
+ * for a handful of short paths; targets with bytes outside ACGT; GASM_LEV_HOST) — same numbers either way */
+int gasm_scores_lev_device(const gasm_scores* s);
 void gasm_scores_free(gasm_scores* s);
 
 /* contig_frac_len of lib/DeNovoAssembler.R:432-445: percentage of [1, seq_len] covered by the union of the inclusive

@@ -658,7 +658,7 @@ static inline uint64_t sim_mix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 uint64_t orc_simulate_starts(const char* genome, uint64_t L, uint32_t seg_index, uint32_t read_len, double coverage, uint64_t seed,
-                             int kmer, const char* kd, const uint64_t* koff, uint64_t nk, const double* prob, uint32_t* out_starts) {
+                             int kmer, const char* kd, const uint64_t* koff, uint64_t nk, const double* prob, int weight_shift, uint32_t* out_starts) {
     if (L < (uint64_t)kmer) return 0;
     const uint64_t np_ = L - kmer + 1;
     std::vector<uint64_t> cum(np_);
@@ -671,7 +671,7 @@ uint64_t orc_simulate_starts(const char* genome, uint64_t L, uint32_t seg_index,
     uint64_t run = 0;
     for (uint64_t p = 0; p < np_; ++p) {
         uint64_t w = 1;
-        if (prob) w = (uint64_t)std::llrint(std::ldexp(t.at(g.substr(p, kmer)), 52));
+        if (prob) w = (uint64_t)std::llrint(std::ldexp(t.at(g.substr(p, kmer)), weight_shift));
         run += w;
         cum[p] = run;
     }

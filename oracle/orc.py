@@ -251,7 +251,18 @@ def coverage_percent(starts, lens, seq_len):
     return f(_p(a), _p(b), C.c_uint64(len(a)), C.c_int64(seq_len))
 
 
-def simulate_starts(genome, seg_index, read_len, coverage, seed, kmer=8, bp_kmer=None, bp_prob=None):
+def sim_weight_shift(genome_lengths, kmer, bp_kmer, bp_prob):
+    """the fixed-point shift of the weighted simulator for a batch of genomes: 52, lowered until the largest weight times the
+    most start positions of any genome stays below 2^62 (a segment's running sum must not wrap)"""
+    max_p = max((p for key, p in zip(bp_kmer, bp_prob) if len(key) == kmer), default=0.0)
+    max_np = max([max(L - kmer + 1, 0) for L in genome_lengths] + [1])
+    shift = 52
+    while shift > 0 and float(np.ldexp(max_p, shift)) * float(max_np) >= 4611686018427387904.0:
+        shift -= 1
+    return shift
+
+
+def simulate_starts(genome, seg_index, read_len, coverage, seed, kmer=8, bp_kmer=None, bp_prob=None, weight_shift=52):
     """lib/GenerateReads.R:235-313 with the build's pinned random stream: kept 0-based read starts, in draw order"""
     g = genome.encode() if isinstance(genome, str) else bytes(genome)
     nd = int(np.ceil(coverage * len(g) / read_len)) + 1
@@ -262,8 +273,8 @@ def simulate_starts(genome, seg_index, read_len, coverage, seed, kmer=8, bp_kmer
         kb, ko = _pack(bp_kmer)
         prob = np.ascontiguousarray(bp_prob, dtype=np.float64)
         n = f(g, C.c_uint64(len(g)), C.c_uint32(seg_index), C.c_uint32(read_len), C.c_double(coverage), C.c_uint64(seed), C.c_int(kmer), kb, _p(ko),
-              C.c_uint64(len(bp_kmer)), _p(prob), _p(out))
+              C.c_uint64(len(bp_kmer)), _p(prob), C.c_int(weight_shift), _p(out))
     else:
         n = f(g, C.c_uint64(len(g)), C.c_uint32(seg_index), C.c_uint32(read_len), C.c_double(coverage), C.c_uint64(seed), C.c_int(kmer), None, None,
-              C.c_uint64(0), None, _p(out))
+              C.c_uint64(0), None, C.c_int(weight_shift), _p(out))
     return out[:int(n)].copy()

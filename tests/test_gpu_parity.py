@@ -738,6 +738,17 @@ def test_read_simulator_against_oracle(qtable):
             assert dk == ref["distinct"] and dm.tolist() == ref["counts"].tolist()
         b.close()
         t.close()
+    # kmer = 2 on a 100 kb genome: with a shift of 52 the segment's running sum would pass 2^64 (p ~ 1/16 each, 10^5 of them)
+    big = synth.make_segment(9100, 100000, planted=True).tobytes().decode()
+    sh = orc.sim_weight_shift([len(big), len(gs[1])], 2, keys, prob)
+    assert sh < 52
+    b = ga.SegmentBatch.simulate([big, gs[1]], 50, 2.0, 9, kmer=2, table=prob)
+    seg, starts = b.read_starts()
+    for s, g in enumerate((big, gs[1])):
+        ref = orc.simulate_starts(g, s, 50, 2.0, 9, 2, keys, prob, weight_shift=sh)
+        assert starts[int(seg[s]):int(seg[s + 1])].tolist() == ref.tolist(), s
+    assert len(set(starts[:int(seg[1])].tolist())) > 3000            # (a wrapped CDF sent most draws to a few positions)
+    b.close()
     # weights steer the draws: two 8-mers with very different probabilities, counted over many draws
     g = gs[0]
     b = ga.SegmentBatch.simulate([g], 20, 400.0, 11, kmer=8, table=prob)
@@ -836,6 +847,38 @@ def test_guided_traversal_against_own_restatement(qtable):
             assert np.abs(np.array([d["bp_score"] for d in g[s]]) - o["bp_score"]).max(initial=0.0) < TOL
         assert len(g[n_seg]) == len(contigs[n_seg])                              # nothing to chain without branching nodes... or all chained
         b.close()
+
+
+@pytest.mark.timeout(900)
+def test_guided_traversal_at_configs4_size(qtable):
+    """Row A16 at the size BASELINE configs[4] names: 50 kb segments, 250 bp reads at 100x, k = 51 (128-bit keys) — two
+    segments, the steering sums recomputed read by read by the CPU restatement, the guided scaffolds equal as strings and in
+    order, their scores equal to the oracle scorer's.  (Parity unpinned by the reference: the mode is this project's own.)"""
+    from oracle import guided_oracle
+    keys, prob = qtable
+    table = dict(zip(keys, prob.tolist()))
+    k, rl, n_seg, L = 51, 250, 2, 50000
+    reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, 100, seed0=1234, planted=True)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    b.build(k, genome_len_hint=L).score(8, prob)
+    contigs = b.contigs()
+    fx, shift = b.score_fixed()
+    sc = b.scores()
+    g = b.guided()
+    for s in range(n_seg):
+        rs = _strs(reads[int(seg_off[s]):int(seg_off[s + 1])])
+        a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+        assert len(contigs[s]) > 20                                            # the planted repeats branch the graph
+        ofx = guided_oracle.fixed_sums(contigs[s], rs, table, 8, shift)
+        assert ofx == fx[a:e].tolist(), s
+        want = guided_oracle.guided_paths(contigs[s], ofx, k)
+        got = [d["sequence"] for d in g[s]]
+        assert got == want, s
+        assert len(got) < len(contigs[s])                                      # something was chained
+        o = orc.calc_breakscore(got, rs, "", 8, keys, prob, with_lev=False, with_freq=False)
+        assert [d["kmer_breaks"] for d in g[s]] == o["kmer_breaks"].tolist()
+        assert np.abs(np.array([d["bp_score"] for d in g[s]]) - o["bp_score"]).max(initial=0.0) < TOL
+    b.close()
 
 
 @pytest.mark.timeout(180)
