@@ -83,6 +83,8 @@ SYMBOLS = {
     "gasm_batch_simulate": (_int, [_vp, _vp, _vp, _u32, _u32, C.c_double, _u64, _int, _vp, _PP]),
     "gasm_batch_fetch_read_starts": (_int, [_vp, _PP, _PP]),
     "gasm_read_files": (_int, [_vp, _u32, _int, _PP]),
+    "gasm_read_files_device": (_int, [_vp, _vp, _u32, _int, _PP]),
+    "gasm_packed_parsed_on_device": (_int, [_vp, _u32]),
     "gasm_packed_n_reads": (_u64, [_vp]),
     "gasm_packed_n_segments": (_u32, [_vp]),
     "gasm_packed_words": (_vp, [_vp]),

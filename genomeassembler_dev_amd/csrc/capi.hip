@@ -28,6 +28,7 @@ struct gasm_packed {
     gasm_host::PackedReads pr;
     std::vector<u64> seg;
     u64 dropped = 0;
+    std::vector<u8> on_device;       // per file: parsed and packed by the device path (gasm_read_files_device)
 };
 
 struct gasm_scores {
@@ -612,21 +613,55 @@ const uint64_t* gasm_packed_seg_read_off(const gasm_packed* g) { return g ? g->s
 uint64_t gasm_packed_dropped(const gasm_packed* g) { return g ? g->dropped : 0; }
 void gasm_packed_free(gasm_packed* g) { delete g; }
 
+// the same files through the device path (ingest.hip: record scan + 2-bit pack on the GPU, the host only inflates), results
+// copied back: what gasm_batch_from_files builds its batch from without the copy
+int gasm_read_files_device(gasm_ctx* ctx, const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_packed** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || !paths || n_files == 0) { gasm_set_error("gasm_read_files_device: bad argument"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    gasm_packed* g = new gasm_packed();
+    DBuf d_words;
+    struct Rel { DBuf& b; ~Rel() { b.release(); } } rel{d_words};
+    const int st = ingest_files_device(ctx, paths, n_files, on_non_acgt != 0, d_words, g->pr.read_off, g->seg, &g->dropped, g->on_device);
+    if (st != GASM_OK) { delete g; return st; }
+    g->pr.total_bases = g->pr.read_off.back();
+    const u64 nw = (g->pr.total_bases + 31) / 32;
+    g->pr.words.resize(nw);
+    if (nw && hipMemcpy(g->pr.words.data(), d_words.p, nw * 8, hipMemcpyDeviceToHost) != hipSuccess) { delete g; gasm_set_error("copy of the packed reads failed"); return GASM_ERR_HIP; }
+    *out = g;
+    return GASM_OK;
+    API_GUARD_END
+}
+int gasm_packed_parsed_on_device(const gasm_packed* g, uint32_t file) { return g && file < g->on_device.size() ? g->on_device[file] : 0; }
+
 int gasm_batch_from_files(gasm_ctx* ctx, const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_batch** out, uint64_t* dropped_reads) {
     API_GUARD_BEGIN
     if (!ctx || !out || !paths || n_files == 0) { gasm_set_error("gasm_batch_from_files: bad argument"); return GASM_ERR_INVALID; }
     *out = nullptr;
-    gasm_packed g;
-    GCHK(parse_files(paths, n_files, on_non_acgt, g));
-    gasm_host::PackedReads& pr = g.pr;
-    std::vector<u64>& seg = g.seg;
-    if (dropped_reads) *dropped_reads = g.dropped;
-    const u64 n = pr.read_off.size() - 1;
+    // record scan and 2-bit packing on the device (ingest.hip); the packed stream never leaves it
+    DBuf d_words;
+    struct Rel { DBuf& b; ~Rel() { b.release(); } } rel{d_words};
+    std::vector<u64> read_off, seg;
+    std::vector<u8> on_device;
+    u64 dropped = 0;
+    GCHK(ingest_files_device(ctx, paths, n_files, on_non_acgt != 0, d_words, read_off, seg, &dropped, on_device));
+    if (dropped_reads) *dropped_reads = dropped;
+    const u64 n = read_off.size() - 1;
     // fixed-length reads (the usual case) need no offset array on the device
-    u32 flen = n ? (u32)std::min<u64>(pr.read_off[1], 0xFFFFFFFFull) : 0;
+    u32 flen = n ? (u32)std::min<u64>(read_off[1], 0xFFFFFFFFull) : 0;
     bool fixed = n > 0 && flen > 0;
-    for (u64 r = 0; fixed && r < n; ++r) fixed = pr.read_off[r + 1] - pr.read_off[r] == flen;
-    return batch_from_packed(ctx, pr.words.data(), fixed ? nullptr : pr.read_off.data(), n, fixed ? flen : 0, seg.data(), n_files, out);
+    for (u64 r = 0; fixed && r < n; ++r) fixed = read_off[r + 1] - read_off[r] == flen;
+    gasm_batch* b = new gasm_batch();
+    b->ctx = ctx;
+    b->n_segments = n_files;
+    b->n_reads = n;
+    b->sub.resize(1);
+    SubBatch& sb = b->sub[0];
+    sb.cx = ctx; sb.seg0 = 0; sb.seg1 = n_files;
+    const int st = sb.rd.adopt_packed(ctx, d_words, fixed ? nullptr : read_off.data(), n, fixed ? flen : 0, seg.data(), n_files);
+    if (st != GASM_OK) { gasm_batch_free(b); return st; }
+    *out = b;
+    return GASM_OK;
     API_GUARD_END
 }
 

@@ -26,6 +26,7 @@ struct DevReads {
                u32 n_segments);
     int upload_packed(gasm_ctx* ctx, const u64* words, const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off,
                       u32 n_segments);
+    int adopt_packed(gasm_ctx* ctx, DBuf& words_dev, const u64* read_off, u64 n_reads, u32 fixed_len, const u64* seg_read_off, u32 n_segments);
     // reads simulated on the device from the genomes (lib/GenerateReads.R:235-313); d_kept_start receives every read's start
     int simulate(gasm_ctx* ctx, const char* genomes, const u64* genome_off, u32 n_segments, u32 read_len, double coverage, u64 seed, int kmer,
                  const double* table, DBuf& d_kept_start);
@@ -168,3 +169,7 @@ int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 ta
 // wait for `ticket` to appear at `word` (pinned memory written last by a kernel of the ctx stream); spin, then poll with a deadline
 int gasm_wait_word32(gasm_ctx* ctx, const volatile u32* word, u32 ticket);
 int gasm_wait_word64(gasm_ctx* ctx, const volatile u64* word, u64 ticket);
+
+// sequence files parsed and packed on the device (ingest.hip); on_device[f] = 0 where the host reader took an irregular file
+int ingest_files_device(gasm_ctx* ctx, const char* const* paths, u32 n_files, bool error_on_non_acgt, DBuf& d_words, std::vector<u64>& read_off,
+                        std::vector<u64>& seg, u64* dropped, std::vector<u8>& on_device);

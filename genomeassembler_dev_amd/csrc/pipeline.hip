@@ -214,6 +214,19 @@ int DevReads::upload_packed(gasm_ctx* ctx, const u64* words, const u64* read_off
     return finish_upload(ctx);
 }
 
+// Reads packed on the device already (ingest.hip): the stream is taken over as it is (zero beyond its last base, padding words
+// included); only the directories come from the host.
+int DevReads::adopt_packed(gasm_ctx* ctx, DBuf& words_dev, const u64* read_off, u64 n, u32 flen, const u64* seg_off, u32 S) {
+    if (!ctx) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
+    GCHK(set_layout(read_off, n, flen, seg_off, S));
+    HIPCHK(hipSetDevice(ctx->device));
+    const u64 nw = (total_bases + 31) / 32;
+    if (words_dev.cap < (nw + 4) * 8) { gasm_set_error("adopt_packed: the stream is shorter than its directories say"); return GASM_ERR_INVALID; }
+    d_words.release();
+    std::swap(d_words, words_dev);
+    return finish_upload(ctx);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Simulated reads, made on the device (kernels_sim.hip; lib/GenerateReads.R:235-313)
 // ---------------------------------------------------------------------------------------------------------------

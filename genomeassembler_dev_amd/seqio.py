@@ -30,6 +30,25 @@ def read_files(paths, non_acgt="drop"):
         L.gasm_packed_free(h)
 
 
+def read_files_device(paths, non_acgt="drop", ctx=None):
+    """the same through the device path (gasm_read_files_device, csrc/ingest.hip: the host inflates, the GPU finds the records
+    and packs them) -> (words, read_off, seg_read_off, dropped, parsed_on_device[bool per file])"""
+    from ._lib import default_context
+    ctx = ctx or default_context()
+    h = C.c_void_p()
+    check(lib().gasm_read_files_device(ctx.h, _paths(paths), len(paths), 1 if non_acgt == "error" else 0, C.byref(h)))
+    L = lib()
+    try:
+        n, S = L.gasm_packed_n_reads(h), L.gasm_packed_n_segments(h)
+        off = np.ctypeslib.as_array(C.cast(L.gasm_packed_read_off(h), C.POINTER(C.c_uint64)), shape=(n + 1,)).copy()
+        seg = np.ctypeslib.as_array(C.cast(L.gasm_packed_seg_read_off(h), C.POINTER(C.c_uint64)), shape=(S + 1,)).copy()
+        nw = (int(off[-1]) + 31) // 32
+        words = np.ctypeslib.as_array(C.cast(L.gasm_packed_words(h), C.POINTER(C.c_uint64)), shape=(nw,)).copy() if nw else np.zeros(0, np.uint64)
+        return words, off, seg, int(L.gasm_packed_dropped(h)), [bool(L.gasm_packed_parsed_on_device(h, f)) for f in range(len(paths))]
+    finally:
+        L.gasm_packed_free(h)
+
+
 def unpack_reads(words, read_off):
     """packed reads -> list of bytes (for inspection and tests)"""
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)

@@ -213,6 +213,11 @@ int gasm_batch_fetch_read_starts(gasm_batch* b, const uint64_t** seg_read_off, c
 /* the reader alone (host only, no GPU needed): the reads of the files, packed as gasm_batch_create_packed takes them */
 typedef struct gasm_packed gasm_packed;
 int gasm_read_files(const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_packed** out);
+/* The same through the device path (csrc/ingest.hip): the host opens and inflates the file, the GPU finds the records (newline
+ * scan), validates and 2-bit packs them; a text it does not recognise as plain four-line FASTQ or FASTA goes to the host reader,
+ * whose grammar is the definition (gasm_packed_parsed_on_device(g, file) = 0 then).  Same results as gasm_read_files. */
+int gasm_read_files_device(gasm_ctx* ctx, const char* const* paths, uint32_t n_files, int on_non_acgt, gasm_packed** out);
+int gasm_packed_parsed_on_device(const gasm_packed* g, uint32_t file);
 uint64_t gasm_packed_n_reads(const gasm_packed* g);
 uint32_t gasm_packed_n_segments(const gasm_packed* g);
 const uint64_t* gasm_packed_words(const gasm_packed* g);
