@@ -147,7 +147,7 @@ __global__ void k_unpack_ascii(const u64* words, u64 nbases, u8* out);
 __global__ void k_guided_chain(PathSet ps, const unsigned long long* fx, int k, u32* g_next, u32* g_prev);
 __global__ void k_asm_match(const u64* cwords, const u64* c_off, u32 n, int k, u8* match, u8* row_any, u8* level_any);
 __global__ void k_asm_merge(const u32* perm, u32 rows, u32 n, int k, const u32* clen, const u8* match, const u8* row_any, const u8* level_any,
-                            u32* out_next, u8* out_ov, u32* out_heads, u32* out_nchains, u8* need_host);
+                            const u64* cwords, const u64* c_off, u32* out_next, u8* out_ov, u32* out_heads, u32* out_nchains, u8* need_host);
 
 // ---- kernels_sim.hip
 __global__ void k_sim_weights(const u64* gwords, const u64* gbase, const u64* woff, u32 n_segments, int kmer, const long long* fixw, u64* w);

@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(GASM_WG) k_unpack_ascii(const u64* __restrict_
 // One wave per permutation: the outer loops (overlap, repeat-until-stable, i) run as the reference writes them; the inner
 // scan "for j from the back, the first chain whose head matches my tail" is 64 candidates per step with a ballot; the
 // chain table lives in LDS.  Two chains of equal length whose tail/head match need the reference's full-string test
-// `c[i] != c[j]`: such a permutation is handed back to the host routine (need_host), it is rare.
+// `c[i] != c[j]`: made on the device too (chains_equal walks both chains through the packed contigs) — until round 3 such a
+// permutation went back to the host routine, and with 52 contigs two of equal length meet in two rows out of three.
 // ================================================================================================================
 __global__ void __launch_bounds__(GASM_WG) k_asm_match(const u64* __restrict__ cwords, const u64* __restrict__ c_off, u32 n, int k,
                                                        u8* __restrict__ match, u8* __restrict__ row_any, u8* __restrict__ level_any) {
@@ -111,9 +112,29 @@ __global__ void __launch_bounds__(GASM_WG) k_asm_match(const u64* __restrict__ c
     }
 }
 
+// Are the strings of two chains of equal length the same?  (lib/DeNovoAssembler.cpp:238: `contigs[i] != contigs[j]` — at equal
+// length only the full comparison tells.)  A chain is its head contig followed by every next contig minus the overlap; both
+// are walked in pieces of up to 32 bases.  Every lane runs the same loop (uniform control flow, uniform loads); chains of
+// distinct contigs differ within the first word almost always.
+__device__ __forceinline__ bool chains_equal(const u64* __restrict__ cwords, const u64* __restrict__ c_off, const u32* next, const u8* ovl, u32 ha, u32 hb, u32 len) {
+    u32 ca = ha, cb = hb;
+    u64 pa = c_off[ca], ea = c_off[ca + 1], pb = c_off[cb], eb = c_off[cb + 1];
+    u32 left = len;
+    while (left) {
+        while (pa == ea) { const u32 o = ovl[ca]; ca = next[ca]; if (ca == GASM_NONE32) return true; pa = c_off[ca] + o; ea = c_off[ca + 1]; }
+        while (pb == eb) { const u32 o = ovl[cb]; cb = next[cb]; if (cb == GASM_NONE32) return true; pb = c_off[cb] + o; eb = c_off[cb + 1]; }
+        const u32 m = (u32)min(min(ea - pa, eb - pb), (u64)min(32u, left));
+        const u64 mk = m == 32 ? ~0ull : ~0ull << (64 - 2 * m);
+        if ((window32(cwords, pa) & mk) != (window32(cwords, pb) & mk)) return false;
+        pa += m; pb += m; left -= m;
+    }
+    return true;
+}
+
 __global__ void __launch_bounds__(64) k_asm_merge(const u32* __restrict__ perm, u32 rows, u32 n, int k, const u32* __restrict__ clen,
                                                   const u8* __restrict__ match, const u8* __restrict__ row_any, const u8* __restrict__ level_any,
-                                                  u32* __restrict__ out_next, u8* __restrict__ out_ov, u32* __restrict__ out_heads,
+                                                  const u64* __restrict__ cwords, const u64* __restrict__ c_off,
+                                                  u32* out_next, u8* out_ov, u32* __restrict__ out_heads,
                                                   u32* __restrict__ out_nchains, u8* __restrict__ need_host) {
     extern __shared__ u32 sm[];
     u32* head = sm;
@@ -149,7 +170,9 @@ __global__ void __launch_bounds__(64) k_asm_merge(const u32* __restrict__ perm, 
                         const unsigned long long mask = __ballot(ok);
                         if (!mask) { jtop -= 64; continue; }
                         const int j = jtop - (__ffsll((long long)mask) - 1);      // the highest matching position
-                        if (len[i] == len[j]) { bad = true; break; }              // c[i] == c[j] possible: the host's string test
+                        // c[i] == c[j] is possible at equal length only: the reference's full-string test, on the chains as they
+                        // stand (round 2 handed such a permutation back to the host: 68 % of the rows of a 50 kb experiment)
+                        if (len[i] == len[j] && chains_equal(cwords, c_off, out_next + rb, out_ov + rb, head[i], head[j], len[i])) { jtop = j - 1; continue; }
                         __syncthreads();                                          // (everybody has read the old state)
                         if (lane == 0) {
                             out_next[rb + ti] = head[j];

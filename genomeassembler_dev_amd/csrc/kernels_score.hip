@@ -392,81 +392,156 @@ __device__ __forceinline__ int wave_shr1(int v, int lane0) {      // lane b gets
     return __builtin_amdgcn_update_dpp(lane0, v, 0x138, 0xf, 0xf, false);
 }
 
-__global__ void __launch_bounds__(GASM_WG) k_levenshtein(PathSet ps, u32 n_paths, const u64* __restrict__ twords, u32 nt, int infix,
-                                                         u8* __restrict__ carry_ws, u64 carry_stride, int32_t* __restrict__ out) {
+// Round 3: the column step costs about half the instructions of round 2's (117 -> ~60, ISA count) —
+//   * a lane's four match masks (one per target base, the valid rows folded in) are made once per band and picked with two
+//     bit-selects, instead of rebuilding the comparison from two code planes at every column;
+//   * the horizontal delta travels as two bits (+1 / -1) packed with the target base in one register: one wave shift per step;
+//   * the chunks of 64 columns in which every lane is inside its band (all but the first and the last one or two of ~780)
+//     run a body without any "is this lane active" select; the others keep the predicated body;
+//   * the delta leaving the band's last block goes from lane 63 to "its" lane with a readlane / writelane pair, stored once
+//     per 64 columns; the score is a 32-bit add under a per-lane mask.
+// lane LANE of `old` := sval (v_writelane_b32; this clang has no builtin for it, and the instruction takes one SGPR only: the
+// lane select is an immediate, so the chunk body that uses it is unrolled).  The nops cover the wait states the ISA asks for
+// after the instruction that wrote the SGPR.
+template <int LANE>
+__device__ __forceinline__ int lev_writelane(int old, int sval) {
+    __asm__ volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(LANE));
+    return old;
+}
+
+struct LevLane {
+    u64 P[4];          // rows of this block that match target base c, valid rows only
+    u64 Pv, Mv;
+    u32 tb;            // bit of the block's last row (63, or less in the path's last block)
+    int smask;         // -1 in the lane that holds the path's last row (and only in the last band)
+};
+
+template <bool PRED>
+__device__ __forceinline__ void lev_step(LevLane& L, u32& pk, u32 inj, bool act, int& score) {
+    // pk: this lane's (target base | pos << 2 | neg << 3) of the column it has just finished; it becomes the next lane's input
+    const u32 x = (u32)__builtin_amdgcn_update_dpp((int)inj, (int)pk, 0x138, 0xf, 0xf, false);      // wave_shr:1, lane 0 keeps inj
+    // the target base picks one of the four match masks: two levels of bit-select on 32-bit halves (v_bfe_i32 + v_bfi_b32; written
+    // with 64-bit masks the compiler built them with carry chains)
+    const u32 m0 = (u32)__builtin_amdgcn_sbfe((int)x, 0, 1), m1 = (u32)__builtin_amdgcn_sbfe((int)x, 1, 1);      // all ones / zero
+    const u64 pos = (x >> 2) & 1u, neg = (x >> 3) & 1u;
+    auto sel = [](u32 m, u32 a, u32 b) { return (a & m) | (b & ~m); };
+    const u32 e_lo = sel(m1, sel(m0, (u32)L.P[3], (u32)L.P[2]), sel(m0, (u32)L.P[1], (u32)L.P[0]));
+    const u32 e_hi = sel(m1, sel(m0, (u32)(L.P[3] >> 32), (u32)(L.P[2] >> 32)), sel(m0, (u32)(L.P[1] >> 32), (u32)(L.P[0] >> 32)));
+    const u64 eq0 = (u64)e_lo | ((u64)e_hi << 32);
+    const u64 xv = eq0 | L.Mv;
+    const u64 eq = eq0 | neg;
+    const u64 xh = (((eq & L.Pv) + L.Pv) ^ L.Pv) | eq;
+    const u64 ph0 = L.Mv | ~(xh | L.Pv), mh0 = L.Pv & xh;
+    const u32 hp = (u32)(ph0 >> L.tb) & 1u, hn = (u32)(mh0 >> L.tb) & 1u;
+    const u64 ph = (ph0 << 1) | pos, mh = (mh0 << 1) | neg;
+    const u64 nPv = mh | ~(xv | ph), nMv = ph & xv;
+    const u32 npk = (x & 3u) | (hp << 2) | (hn << 3);
+    if (PRED) {
+        L.Pv = act ? nPv : L.Pv;
+        L.Mv = act ? nMv : L.Mv;
+        pk = act ? npk : ((x & 3u) | (pk & 12u));      // the base moves on; the delta of a lane outside its band stays what it was
+        score += act ? (((int)hp - (int)hn) & L.smask) : 0;
+    } else {
+        L.Pv = nPv; L.Mv = nMv; pk = npk;
+        score += ((int)hp - (int)hn) & L.smask;
+    }
+}
+
+// 64 columns in which every lane is inside its band: no "is this lane active" select anywhere
+template <bool INFIX, bool LAST_BAND>
+__device__ __forceinline__ void lev_chunk(LevLane& L, u32& pk, u32 inj_all, int& score, int& best, int& cout, u8* __restrict__ carry, u32 s0, u32 ln) {
+    static_for<64>([&](auto T) {
+        constexpr u32 t = T;
+        const u32 inj = (u32)__builtin_amdgcn_readlane((int)inj_all, (int)t);
+        lev_step<false>(L, pk, inj, true, score);
+        if (INFIX) best = score < best ? score : best;
+        if (!LAST_BAND) {
+            const int h63 = __builtin_amdgcn_readlane((int)((pk >> 2) & 3u), 63);       // pos | neg << 1 of column s0 + t - 63
+            cout = lev_writelane<(int)((t + 1) & 63u)>(cout, h63);
+            if (t == 62) {
+                // columns s0 - 64 .. s0 - 1 are complete: bits -> the byte code (delta + 1) the next band reads
+                const u32 c2 = (u32)cout;
+                carry[s0 - 64 + ln] = (u8)(1u + (c2 & 1u) - ((c2 >> 1) & 1u));
+            }
+        }
+    });
+}
+
+template <bool INFIX>
+__device__ __forceinline__ void lev_path(const PathSet& ps, u32 p, const u64* __restrict__ twords, u32 nt, u8* __restrict__ carry, int32_t* __restrict__ out) {
     const u32 ln = threadIdx.x & 63;
-    const u32 wave = (blockIdx.x * GASM_WG + threadIdx.x) >> 6, n_waves = gridDim.x * (GASM_WG / 64);
-    u8* const carry = carry_ws + (u64)wave * carry_stride;         // nt + 64 bytes of this wave
-    for (u32 p = wave; p < n_paths; p += n_waves) {
-        const u64 pb = ps.p_off[p];
-        const u32 nq = (u32)(ps.p_off[p + 1] - pb);
-        if (nq == 0 || nt == 0) { if (ln == 0) out[p] = 0; continue; }     // edlib reports an error, the reference returns 0
-        const u32 nblk = (nq + 63) / 64, nbands = (nblk + 63) / 64;
-        const u32 last_lane = (nblk - 1) & 63;
-        long long score = nq, best = nq;
-        for (u32 band = 0; band < nbands; ++band) {
-            // ---- this lane's block: match masks as two code planes, valid rows, top row
-            const u32 blk = band * 64 + ln;
-            u64 H = 0, L = 0, valid = 0;
-            if (blk < nblk) {
+    const u64 pb = ps.p_off[p];
+    const u32 nq = (u32)(ps.p_off[p + 1] - pb);
+    if (nq == 0 || nt == 0) { if (ln == 0) out[p] = 0; return; }     // edlib reports an error, the reference returns 0
+    const u32 nblk = (nq + 63) / 64, nbands = (nblk + 63) / 64;
+    const u32 last_lane = (nblk - 1) & 63;
+    int score = (int)nq, best = (int)nq;
+    for (u32 band = 0; band < nbands; ++band) {
+        const u32 blk = band * 64 + ln;
+        const bool mine = blk < nblk, last_band = band + 1 == nbands;
+        LevLane L;
+        {
+            u64 H = 0, Lo = 0, valid = 0;
+            if (mine) {
                 const u32 rows = min(64u, nq - blk * 64);
                 u32 h0, l0, h1 = 0, l1 = 0;
                 code_planes32(window32(ps.words, pb + (u64)blk * 64), &h0, &l0);
                 if (rows > 32) code_planes32(window32(ps.words, pb + (u64)blk * 64 + 32), &h1, &l1);
                 H = (u64)h0 | ((u64)h1 << 32);
-                L = (u64)l0 | ((u64)l1 << 32);
+                Lo = (u64)l0 | ((u64)l1 << 32);
                 valid = rows == 64 ? ~0ull : ((1ull << rows) - 1);
             }
-            const u64 top = blk + 1 == nblk ? (1ull << ((nq - 1) & 63)) : (1ull << 63);
-            const bool last_band = band + 1 == nbands;
-            u64 Pv = ~0ull, Mv = 0;
-            int hout = 0, ch = 0;
-            const int hin0 = infix ? 0 : 1;                       // delta entering block 0 (lib/BreakageScorer.cpp: HW mode)
-            const bool mine = blk < nblk;
-            const bool scorer = last_band && ln == last_lane;
-            u32 cout = 0;                                         // deltas leaving the band, columns [s0 - 64, s0) of the chunk before
-            // columns in chunks of 64: lane l holds the target code and the incoming delta of column s0 + l; step s of
-            // the chunk takes lane s of them for lane 0 (the straight-line body below has no branch)
-            for (u32 s0 = 0; s0 < nt + 63; s0 += 64) {
-                const u32 jl = s0 + ln;
-                const u32 tch = jl < nt ? (u32)(twords[jl >> 5] >> (62 - 2 * (jl & 31))) & 3u : 0u;
-                const u32 cin = (band && jl < nt) ? (u32)carry[jl] : 1u;
-                const u32 steps = min(64u, nt + 63 - s0);
+            L.P[0] = ~H & ~Lo & valid; L.P[1] = ~H & Lo & valid; L.P[2] = H & ~Lo & valid; L.P[3] = H & Lo & valid;
+            L.Pv = ~0ull; L.Mv = 0;
+            L.tb = blk + 1 == nblk ? ((nq - 1) & 63) : 63u;
+            L.smask = (last_band && ln == last_lane) ? -1 : 0;
+        }
+        // delta entering block 0 of the first band: +1 (global) / 0 (infix, lib/BreakageScorer.cpp: HW mode)
+        const u32 hin0 = INFIX ? 0u : 4u;
+        u32 pk = 0;               // (a lane before its band hands on "no delta": never consumed)
+        int cout = 0;             // deltas leaving the band (+1 coded), the lane of column c is c & 63
+        for (u32 s0 = 0; s0 < nt + 63; s0 += 64) {
+            const u32 jl = s0 + ln;
+            const u32 tch = jl < nt ? (u32)(twords[jl >> 5] >> (62 - 2 * (jl & 31))) & 3u : 0u;
+            u32 hbits = hin0;
+            if (band) { const u32 cin = jl < nt ? (u32)carry[jl] : 1u; hbits = (cin == 2u ? 4u : 0u) | (cin == 0u ? 8u : 0u); }
+            const u32 inj_all = tch | hbits;
+            const u32 steps = min(64u, nt + 63 - s0);
+            if (s0 >= 64 && s0 + 64 <= nt) {
+                // ---- every lane is inside its band for all 64 columns of this chunk: no selects
+                if (last_band) lev_chunk<INFIX, true>(L, pk, inj_all, score, best, cout, carry, s0, ln);
+                else lev_chunk<INFIX, false>(L, pk, inj_all, score, best, cout, carry, s0, ln);
+            } else {
                 for (u32 t = 0; t < steps; ++t) {
                     const u32 s = s0 + t;
-                    const int ch_new = (int)__builtin_amdgcn_readlane((int)tch, t);
-                    const int hin_new = band ? (int)__builtin_amdgcn_readlane((int)cin, t) - 1 : hin0;
-                    ch = wave_shr1(ch, ch_new);
-                    const int hin = wave_shr1(hout, hin_new);
+                    const u32 inj = (u32)__builtin_amdgcn_readlane((int)inj_all, (int)t);
                     const bool act = mine && s >= ln && s - ln < nt;
-                    // ---- one column of the block (Hyyro's formulation, as gasm_host::levenshtein), branch-free
-                    const u64 hm = 0ull - (u64)((ch >> 1) & 1), lm = 0ull - (u64)(ch & 1);
-                    const u64 neg = hin < 0 ? 1ull : 0ull, pos = hin > 0 ? 1ull : 0ull;
-                    const u64 eq0 = ~((H ^ hm) | (L ^ lm)) & valid;
-                    const u64 xv = eq0 | Mv;
-                    const u64 eq = eq0 | neg;
-                    const u64 xh = (((eq & Pv) + Pv) ^ Pv) | eq;
-                    const u64 ph0 = Mv | ~(xh | Pv), mh0 = Pv & xh;
-                    const int ho = (ph0 & top) ? 1 : ((mh0 & top) ? -1 : 0);
-                    const u64 ph = (ph0 << 1) | pos, mh = (mh0 << 1) | neg;
-                    const u64 nPv = mh | ~(xv | ph), nMv = ph & xv;
-                    Pv = act ? nPv : Pv;
-                    Mv = act ? nMv : Mv;
-                    hout = act ? ho : hout;
-                    score += (act && scorer) ? ho : 0;
-                    best = score < best ? score : best;
-                    // ---- the delta leaving the band's last block belongs to column s - 63
-                    const int h63 = __builtin_amdgcn_readlane(hout, 63);
-                    cout = ln == ((s - 63) & 63) ? (u32)(h63 + 1) : cout;
-                    if (!last_band && s >= 63 && (((s - 63) & 63) == 63 || s - 62 == nt)) {     // uniform: once per 64 columns
-                        const u32 jj = ((s - 63) & ~63u) + ln;
-                        if (jj < nt) carry[jj] = (u8)cout;
+                    lev_step<true>(L, pk, inj, act, score);
+                    if (INFIX) best = score < best ? score : best;
+                    if (!last_band) {
+                        const int h63 = __builtin_amdgcn_readlane((int)((pk >> 2) & 3u), 63);
+                        cout = ln == ((s - 63) & 63u) ? h63 : cout;
+                        if (s >= 63 && (((s - 63) & 63u) == 63u || s - 62 == nt)) {                  // uniform: once per 64 columns, and at the end
+                            const u32 jj = ((s - 63) & ~63u) + ln;
+                            const u32 c2 = (u32)cout;
+                            if (jj < nt) carry[jj] = (u8)(1u + (c2 & 1u) - ((c2 >> 1) & 1u));
+                        }
                     }
                 }
             }
         }
-        const long long sc = __shfl(infix ? best : score, (int)last_lane, 64);
-        if (ln == 0) out[p] = (int32_t)sc;
+    }
+    const int sc = __shfl(INFIX ? best : score, (int)last_lane, 64);
+    if (ln == 0) out[p] = (int32_t)sc;
+}
+
+__global__ void __launch_bounds__(GASM_WG) k_levenshtein(PathSet ps, u32 n_paths, const u64* __restrict__ twords, u32 nt, int infix,
+                                                         u8* __restrict__ carry_ws, u64 carry_stride, int32_t* __restrict__ out) {
+    const u32 wave = (blockIdx.x * GASM_WG + threadIdx.x) >> 6, n_waves = gridDim.x * (GASM_WG / 64);
+    u8* const carry = carry_ws + (u64)wave * carry_stride;         // nt + 64 bytes of this wave
+    for (u32 p = wave; p < n_paths; p += n_waves) {
+        if (infix) lev_path<true>(ps, p, twords, nt, carry, out);
+        else lev_path<false>(ps, p, twords, nt, carry, out);
     }
 }
 

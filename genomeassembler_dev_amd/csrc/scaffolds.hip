@@ -163,7 +163,7 @@ int assemble_signatures_device(gasm_ctx* ctx, const std::vector<std::string>& co
     GCHK(d_need.ensure(rows));
     const size_t lds = (size_t)n * 13 + 16;
     GLAUNCH(ctx, "k_asm_merge", k_asm_merge, dim3((u32)std::min<u64>(rows, (u64)ctx->n_cu * 32u)), dim3(64), lds, d_perm.as<u32>(), (u32)rows, (u32)n, k, d_clen.as<u32>(),
-            d_match.as<u8>(), d_ra.as<u8>(), d_la.as<u8>(), d_next.as<u32>(), d_ov.as<u8>(), d_heads.as<u32>(), d_nch.as<u32>(), d_need.as<u8>());
+            d_match.as<u8>(), d_ra.as<u8>(), d_la.as<u8>(), cwords.as<u64>(), d_coff.as<u64>(), d_next.as<u32>(), d_ov.as<u8>(), d_heads.as<u32>(), d_nch.as<u32>(), d_need.as<u8>());
     std::vector<u32> next(rows * n), heads(rows * n), nch(rows);
     std::vector<u8> ov(rows * n), need(rows);
     u32 herr = 0;

@@ -37,7 +37,8 @@ timed("calc_breakscore(strings), with lev", lambda: ga.calc_breakscore(sc, reads
 # the same experiment with the scaffolds left on the GPU between the two calls (gasm_assemble_contigs_dev / _calc_breakscore_dev)
 dv = timed("assemble_contigs (on device)", lambda: ga.assemble_contigs(m, k, on_device=True))
 b = timed("calc_breakscore(handle), no lev", lambda: ga.calc_breakscore(dv, reads, truth, 8, keys, prob, with_lev=False, with_freq=False))
-timed("calc_breakscore(handle), lev + KS", lambda: ga.calc_breakscore(dv, reads, truth, 8, keys, prob, with_lev=True, with_freq=False, with_ks=True))
+c = timed("calc_breakscore(handle), lev + KS", lambda: ga.calc_breakscore(dv, reads, truth, 8, keys, prob, with_lev=True, with_freq=False, with_ks=True))
+print(f"  who did the work: greedy merge {dv.merge_device} ({dv.rows_on_host} of {rows} permutations on the host), Levenshtein {c['lev_device']}")
 assert len(dv) == len(sc) and (a["kmer_breaks"] == b["kmer_breaks"]).all() and abs(a["bp_score"] - b["bp_score"]).max() == 0.0
 os.environ["GASM_ASM_HOST"] = "1"
 timed("assemble_contigs (host strings)", lambda: ga.assemble_contigs(m, k))
