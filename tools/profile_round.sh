@@ -18,7 +18,7 @@ stats() {  # name, bench args...
   f=$(find $out/stats_$name -name "*kernel_stats.csv" | head -1)
   cp "$f" $out/${name}_kernel_stats.csv && rm -rf $out/stats_$name
 }
-stats cfg2 --steps 10 --warmup 2 || exit 2
+stats cfg2 || exit 2      # (the default flags: the same command as the bench line)
 stats cfg4 --workload cfg4 --steps 5 --warmup 1 || exit 2
 stats pooled_n1 --mode pooled --steps 3 --warmup 1 || exit 2
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1 || exit 3
