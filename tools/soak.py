@@ -80,6 +80,53 @@ while time.time() - t0 < budget:
                 raise                                      # (too few bucket bits for this input: the documented answer)
         for r in range(world):
             be[r].close()
+    # the same through the library's own exchange (gasm_pool_exchange_build, virtual ranks), two steps on the cached plans
+    if rounds % 2 == 1:
+        world = int(rng.integers(1, 7))
+        bbits = int(min(rng.integers(0, 6), 2 * (k - 1)))
+        bl = []
+        for r in range(world):
+            pr = [p[r::world] for p in parts]
+            o2 = np.concatenate([[0], np.cumsum([x.shape[0] for x in pr])]).astype(np.uint64)
+            bl.append(pooled.GasmBackend(np.concatenate(pr, axis=0), o2, rl))
+        comm = pooled.Comm.virtual(ga.default_context(), world)
+        try:
+            for step in range(2):
+                stats, own = pooled.exchange_build(comm, bl, k, bbits, kmer=8, table=prob)
+                for r in range(world):
+                    a0, b0 = own[r]
+                    for s, d in zip(range(a0, b0), bl[r].results()):
+                        assert d["contigs"] == contigs[s], (tag, "exchange", world, bbits, step, s)
+                        dk, dm = b.distinct_kmers(s)
+                        assert d["distinct"] == dk and d["counts"].tolist() == dm.tolist(), (tag, "exchange counts", world, bbits, step, s)
+                        ca, ce = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+                        assert d["kmer_breaks"].tolist() == sc["kmer_breaks"][ca:ce].tolist(), (tag, "exchange breaks", world, bbits, step, s)
+                        assert np.abs(d["bp_score"] - sc["bp_score"][ca:ce]).max(initial=0.0) < 1e-12, (tag, "exchange score", world, s)
+        except ga.GasmError as e:
+            if "GASM_ERR_CAPACITY" not in str(e):
+                raise                                      # (a bucket no table holds even with all bucket bits: every rank says so together)
+        for x in bl:
+            x.close()
+        comm.close()
+    # the reads as files, parsed and packed on the device, against the host reader
+    if rounds % 4 == 2:
+        import tempfile
+        from genomeassembler_dev_amd import seqio
+        with tempfile.TemporaryDirectory() as td:
+            paths = []
+            for s in range(min(S, 3)):
+                rs = [x.tobytes().decode() for x in reads[off[s]:off[s + 1]]]
+                p = os.path.join(td, f"s{s}.{'fastq' if s % 2 == 0 else 'fa'}")
+                with open(p, "w") as f:
+                    if s % 2 == 0:
+                        f.write("".join(f"@r{i}\n{r}\n+\n{'I' * len(r)}\n" for i, r in enumerate(rs)))
+                    else:
+                        w = int(rng.integers(10, 200))
+                        f.write("".join(f">r{i}\n" + "".join(r[j:j + w] + "\n" for j in range(0, len(r), w)) for i, r in enumerate(rs)))
+                paths.append(p)
+            w_h, o_h, s_h, d_h = seqio.read_files(paths)
+            w_d, o_d, s_d, d_d, on = seqio.read_files_device(paths)
+            assert all(on) and o_d.tolist() == o_h.tolist() and s_d.tolist() == s_h.tolist() and d_d == d_h and np.array_equal(w_d, w_h), (tag, "ingest")
     # device scaffolds of one segment
     if rounds % 4 == 1 and k >= 3:
         s = int(rng.integers(0, S))
