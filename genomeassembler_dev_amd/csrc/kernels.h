@@ -141,8 +141,15 @@ __global__ void k_slice_last(const u32* a, const u64* off, u32 n, u32* out);
 // ---- kernels_asm.hip
 __global__ void k_chain_expand(const u64* cwords, const u64* c_off, const u64* sig_off, const u32* elem_contig, const u32* elem_skip, const u64* elem_pos,
                                const u64* out_off, u32 n_scaffolds, u64* out, u64 n_words);
-__global__ void k_str_bitonic(const u64* words, const u64* off, u32* idx, u32 n_pow2, u32 kk, u32 j);
-__global__ void k_str_adjacent_eq(const u64* words, const u64* off, const u32* idx, u32 n, u8* same_as_prev);
+struct ChainSigs {             // the scaffolds' signatures beside their text (k_str_bitonic skips what two chains share)
+    const u64* sig_off;        // n + 1
+    const u32* elem_contig;
+    const u32* elem_skip;
+    const u64* elem_pos;       // where the element's own bases start in its scaffold
+};
+__global__ void k_str_bitonic(const u64* words, const u64* off, u32* idx, u32 n_pow2, u32 kk, u32 j, ChainSigs cs);
+__global__ void k_str_bitonic_block(const u64* words, const u64* off, u32* idx, u32 n_pow2, u32 kk, u32 j0, ChainSigs cs);
+__global__ void k_str_adjacent_eq(const u64* words, const u64* off, const u32* idx, u32 n, u8* same_as_prev, ChainSigs cs);
 __global__ void k_unpack_ascii(const u64* words, u64 nbases, u8* out);
 __global__ void k_guided_chain(PathSet ps, const unsigned long long* fx, int k, u32* g_next, u32* g_prev);
 __global__ void k_asm_match(const u64* cwords, const u64* c_off, u32 n, int k, u8* match, u8* row_any, u8* level_any);

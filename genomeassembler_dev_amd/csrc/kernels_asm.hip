@@ -52,8 +52,27 @@ __device__ __forceinline__ bool seq_less(const u64* __restrict__ words, u64 oa, 
     return la < lb;
 }
 
+// Scaffolds are chains of whole contigs (signature = contig, (overlap, contig)*): two of them that begin with the same
+// elements are the same string up to where the first differing element starts — so the comparison walks the signatures (a
+// handful of 32-bit words) and only then the bases, from that point on.  Scaffolds of one experiment share thousands of
+// leading bases (52 contigs, 22 053 scaffolds): the plain word-by-word comparison spent its time re-reading them, 120 passes
+// of the bitonic network long (14.5 ms -> see DESIGN.md §6).  sig = nullptr: plain strings.
+__device__ __forceinline__ u64 chain_common(const ChainSigs& cs, u32 a, u32 b, u64 la, u64 lb) {
+    if (!cs.sig_off) return 0;
+    const u64 sa = cs.sig_off[a], sb = cs.sig_off[b];
+    const u32 na = (u32)(cs.sig_off[a + 1] - sa), nb = (u32)(cs.sig_off[b + 1] - sb), n = na < nb ? na : nb;
+    u32 e = 0;
+    while (e < n && cs.elem_contig[sa + e] == cs.elem_contig[sb + e] && cs.elem_skip[sa + e] == cs.elem_skip[sb + e]) ++e;
+    return e < n ? cs.elem_pos[sa + e] : (la < lb ? la : lb);
+}
+__device__ __forceinline__ bool chain_less(const u64* __restrict__ words, const u64* __restrict__ off, const ChainSigs& cs, u32 a, u32 b, bool* eq) {
+    const u64 oa = off[a], la = off[a + 1] - oa, ob = off[b], lb = off[b + 1] - ob;
+    const u64 P = chain_common(cs, a, b, la, lb);
+    return seq_less(words, oa + P, la - P, ob + P, lb - P, eq);
+}
+
 __global__ void __launch_bounds__(GASM_WG) k_str_bitonic(const u64* __restrict__ words, const u64* __restrict__ off, u32* __restrict__ idx, u32 n_pow2,
-                                                         u32 kk, u32 j) {
+                                                         u32 kk, u32 j, ChainSigs cs) {
     const u32 t = blockIdx.x * GASM_WG + threadIdx.x;
     if (t >= (n_pow2 >> 1)) return;
     const u32 lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
@@ -62,19 +81,45 @@ __global__ void __launch_bounds__(GASM_WG) k_str_bitonic(const u64* __restrict__
     if (a == GASM_NONE32 || b == GASM_NONE32) swap = (a == GASM_NONE32 && b != GASM_NONE32);      // padding sorts last
     else {
         bool eq;
-        const bool b_less = seq_less(words, off[b], off[b + 1] - off[b], off[a], off[a + 1] - off[a], &eq);
+        const bool b_less = chain_less(words, off, cs, b, a, &eq);
         swap = b_less || (eq && b < a);            // equal strings: by index (any fixed order will do: they are merged)
     }
     const bool up = (lo & kk) == 0;
     if (swap == up) { idx[lo] = b; idx[hi] = a; }
 }
 
+// the steps j0, j0 / 2, ... 1 of stage kk (j0 <= GASM_WG): every workgroup owns 2 * GASM_WG consecutive positions, keeps their
+// indices in LDS and runs the steps with a barrier in between
+__global__ void __launch_bounds__(GASM_WG) k_str_bitonic_block(const u64* __restrict__ words, const u64* __restrict__ off, u32* __restrict__ idx, u32 n_pow2,
+                                                               u32 kk, u32 j0, ChainSigs cs) {
+    __shared__ u32 s_idx[2 * GASM_WG];
+    const u32 base = blockIdx.x * 2 * GASM_WG;
+    for (u32 q = threadIdx.x; q < 2 * GASM_WG; q += GASM_WG) s_idx[q] = base + q < n_pow2 ? idx[base + q] : GASM_NONE32;
+    __syncthreads();
+    for (u32 j = j0; j > 0; j >>= 1) {
+        const u32 t = threadIdx.x;
+        const u32 lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+        const u32 a = s_idx[lo], b = s_idx[hi];
+        bool swap;
+        if (a == GASM_NONE32 || b == GASM_NONE32) swap = (a == GASM_NONE32 && b != GASM_NONE32);
+        else {
+            bool eq;
+            const bool b_less = chain_less(words, off, cs, b, a, &eq);
+            swap = b_less || (eq && b < a);
+        }
+        const bool up = ((base + lo) & kk) == 0;
+        if (swap == up) { s_idx[lo] = b; s_idx[hi] = a; }
+        __syncthreads();
+    }
+    for (u32 q = threadIdx.x; q < 2 * GASM_WG; q += GASM_WG) if (base + q < n_pow2) idx[base + q] = s_idx[q];
+}
+
 __global__ void __launch_bounds__(GASM_WG) k_str_adjacent_eq(const u64* __restrict__ words, const u64* __restrict__ off, const u32* __restrict__ idx, u32 n,
-                                                             u8* __restrict__ same_as_prev) {
+                                                             u8* __restrict__ same_as_prev, ChainSigs cs) {
     const u32 i = blockIdx.x * GASM_WG + threadIdx.x;
     if (i >= n) return;
     bool eq = false;
-    if (i) { const u32 a = idx[i - 1], b = idx[i]; (void)seq_less(words, off[a], off[a + 1] - off[a], off[b], off[b + 1] - off[b], &eq); }
+    if (i) { const u32 a = idx[i - 1], b = idx[i]; (void)chain_less(words, off, cs, a, b, &eq); }
     same_as_prev[i] = eq ? 1 : 0;
 }
 

@@ -4,9 +4,24 @@
 // to the caller and uploading them again for calc_breakscore — is replaced by chains expanded to 2-bit on the GPU
 // (kernels_asm.hip), sorted and de-duplicated there as strings, and passed on behind a gasm_scaffolds handle.
 #include <algorithm>
+#include <thread>
 
 #include "pipeline.h"
 #include "scaffolds.h"
+
+// GASM_ASM_TIMING=1 (diagnostic): host wall time of the phases of assemble_contigs' device route, to stderr
+#include <chrono>
+struct AsmLap {
+    bool on = getenv("GASM_ASM_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(gasm_ctx* ctx, const char* what) {
+        if (!on) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[asm] %-34s %8.2f ms\n", what, std::chrono::duration<double>(n - t).count() * 1e3);
+        t = n;
+    }
+};
 
 static int up64(gasm_ctx* ctx, DBuf& b, const void* src, size_t bytes) {
     GCHK(b.ensure(bytes ? bytes : 8));
@@ -18,22 +33,44 @@ struct ChainCsr {
     std::vector<u64> sig_off, elem_pos, out_off;
     std::vector<u32> elem_contig, elem_skip;
     void clear() { sig_off.assign(1, 0); out_off.assign(1, 0); elem_pos.clear(); elem_contig.clear(); elem_skip.clear(); }
-    // signature = u32 contig, (u32 overlap, u32 contig)*
-    void add(const std::string& sg, const std::vector<std::string>& contigs) {
-        u32 x;
-        memcpy(&x, sg.data(), 4);
-        u64 pos = 0;
-        elem_contig.push_back(x); elem_skip.push_back(0); elem_pos.push_back(0);
-        pos += contigs[x].size();
-        for (size_t q = 4; q + 8 <= sg.size(); q += 8) {
-            u32 ov, y;
-            memcpy(&ov, sg.data() + q, 4);
-            memcpy(&y, sg.data() + q + 4, 4);
-            elem_contig.push_back(y); elem_skip.push_back(ov); elem_pos.push_back(pos);
-            pos += contigs[y].size() - ov;
+    // signature = u32 contig, (u32 overlap, u32 contig)*.  order[i] = the signature of scaffold i; threads over the scaffolds
+    // (440 000 elements for one 50 kb experiment: 5 ms on one thread)
+    void build(const std::vector<std::string>& sigs, const u32* order, size_t m, const std::vector<std::string>& contigs) {
+        sig_off.assign(m + 1, 0);
+        out_off.assign(m + 1, 0);
+        for (size_t i = 0; i < m; ++i) sig_off[i + 1] = sig_off[i] + (sigs[order ? order[i] : i].size() + 4) / 8;
+        const size_t ne = sig_off[m];
+        elem_pos.resize(ne); elem_contig.resize(ne); elem_skip.resize(ne);
+        std::vector<u64> len(m);
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = std::max(1u, std::min(nt, 16u));
+        if (m < 2048) nt = 1;
+        auto work = [&](unsigned t) {
+            for (size_t i = m * t / nt; i < m * (t + 1) / nt; ++i) {
+                const std::string& sg = sigs[order ? order[i] : i];
+                size_t e = sig_off[i];
+                u32 x;
+                memcpy(&x, sg.data(), 4);
+                u64 pos = 0;
+                elem_contig[e] = x; elem_skip[e] = 0; elem_pos[e] = 0; ++e;
+                pos += contigs[x].size();
+                for (size_t q = 4; q + 8 <= sg.size(); q += 8, ++e) {
+                    u32 ov, y;
+                    memcpy(&ov, sg.data() + q, 4);
+                    memcpy(&y, sg.data() + q + 4, 4);
+                    elem_contig[e] = y; elem_skip[e] = ov; elem_pos[e] = pos;
+                    pos += contigs[y].size() - ov;
+                }
+                len[i] = pos;
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+            for (auto& t : th) t.join();
         }
-        sig_off.push_back(elem_contig.size());
-        out_off.push_back(out_off.back() + pos);
+        for (size_t i = 0; i < m; ++i) out_off[i + 1] = out_off[i] + len[i];
     }
 };
 
@@ -71,23 +108,33 @@ int scaffolds_from_signatures(gasm_ctx* ctx, const std::vector<std::string>& con
                 (u64)cat.size(), (const u64*)nullptr, cwords.as<u64>(), err.as<u32>());
     }
     GCHK(up64(ctx, d_coff, coff.data(), coff.size() * 8));
+    AsmLap lap;
+    lap(ctx, "scaffolds: contigs packed");
     // ---- every distinct chain once, as text-in-2-bit; sort and de-duplicate as strings (lib/DeNovoAssembler.cpp:275-286)
     ChainCsr c1;
-    c1.clear();
-    for (const std::string& sg : sigs) c1.add(sg, contigs);
+    c1.build(sigs, nullptr, sigs.size(), contigs);
+    lap(ctx, "scaffolds: chain CSR (host)");
     GCHK(expand(ctx, c1, cwords.as<u64>(), d_coff.as<u64>(), d_w1, tmp));
+    lap(ctx, "scaffolds: expand 1");
     u32 p2 = 1;
     while (p2 < m) p2 <<= 1;
     std::vector<u32> idx(p2, GASM_NONE32);
     for (u32 i = 0; i < m; ++i) idx[i] = i;
     GCHK(up64(ctx, d_idx, idx.data(), (size_t)p2 * 4));
-    for (u32 kk = 2; kk <= p2; kk <<= 1)
-        for (u32 j = kk >> 1; j > 0; j >>= 1)
+    const ChainSigs cs{getenv("GASM_ASM_PLAIN_SORT") ? nullptr : tmp[0].as<u64>(), tmp[1].as<u32>(), tmp[2].as<u32>(), tmp[3].as<u64>()};
+    // bitonic network on the index array; the steps whose partners lie inside one 512-element block (j <= 256) of a stage run as
+    // ONE launch with the indices in LDS (120 launches -> 36 for 32 768 scaffolds)
+    for (u32 kk = 2; kk <= p2; kk <<= 1) {
+        u32 j = kk >> 1;
+        for (; j > GASM_WG; j >>= 1)
             GLAUNCH(ctx, "k_str_bitonic", k_str_bitonic, dim3(std::max(1u, ceil_div_u64(p2 >> 1, GASM_WG))), dim3(GASM_WG), 0, d_w1.as<u64>(), tmp[4].as<u64>(),
-                    d_idx.as<u32>(), p2, kk, j);
+                    d_idx.as<u32>(), p2, kk, j, cs);
+        GLAUNCH(ctx, "k_str_bitonic_block", k_str_bitonic_block, dim3(std::max(1u, ceil_div_u64(p2 >> 1, GASM_WG))), dim3(GASM_WG), 0, d_w1.as<u64>(), tmp[4].as<u64>(),
+                d_idx.as<u32>(), p2, kk, j, cs);
+    }
     GCHK(d_same.ensure(std::max<u32>(m, 1)));
     if (m) GLAUNCH(ctx, "k_str_adjacent_eq", k_str_adjacent_eq, dim3(ceil_div_u64(m, GASM_WG)), dim3(GASM_WG), 0, d_w1.as<u64>(), tmp[4].as<u64>(), d_idx.as<u32>(), m,
-                   d_same.as<u8>());
+                   d_same.as<u8>(), cs);
     std::vector<u8> same(m);
     u32 herr = 0;
     HIPCHK(hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -96,6 +143,7 @@ int scaffolds_from_signatures(gasm_ctx* ctx, const std::vector<std::string>& con
         HIPCHK(hipMemcpyAsync(same.data(), d_same.p, m, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    lap(ctx, "scaffolds: string sort + unique");
     if (herr) { gasm_set_error("contigs contain a base outside upper-case ACGT"); return GASM_ERR_NON_ACGT; }
     // ---- the reference's last step: the sorted distinct strings, then std::sort by length, longest first
     // (lib/DeNovoAssembler.cpp:289-294: not a stable sort; the same libstdc++ call on the same initial order makes the same
@@ -106,14 +154,19 @@ int scaffolds_from_signatures(gasm_ctx* ctx, const std::vector<std::string>& con
     std::sort(fin.begin(), fin.end(), [](const Ent& a, const Ent& b) { return a.len > b.len; });
     // ---- the distinct scaffolds in their final order, once more, as the handle's stream
     ChainCsr c2;
-    c2.clear();
-    for (const Ent& e : fin) c2.add(sigs[e.id], contigs);
+    {
+        std::vector<u32> order(fin.size());
+        for (size_t i = 0; i < fin.size(); ++i) order[i] = fin[i].id;
+        c2.build(sigs, order.data(), order.size(), contigs);
+    }
     gasm_scaffolds* sc = new gasm_scaffolds();
     sc->ctx = ctx;
     sc->n = (u32)fin.size();
     sc->h_off = c2.out_off;
+    lap(ctx, "scaffolds: length sort + CSR 2 (host)");
     int st = expand(ctx, c2, cwords.as<u64>(), d_coff.as<u64>(), sc->d_words, tmp);
     if (st == GASM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { gasm_set_error("scaffold expansion failed"); st = GASM_ERR_HIP; }
+    lap(ctx, "scaffolds: expand 2");
     if (st != GASM_OK) { sc->d_words.release(); delete sc; return st; }
     *out = sc;
     return GASM_OK;
@@ -134,6 +187,7 @@ int assemble_signatures_device(gasm_ctx* ctx, const std::vector<std::string>& co
     DBuf ascii, err, cwords, d_coff, d_clen, d_perm, d_match, d_ra, d_la, d_next, d_ov, d_heads, d_nch, d_need;
     struct Rel { std::vector<DBuf*> v; ~Rel() { for (DBuf* b : v) b->release(); } } rel{{&ascii, &err, &cwords, &d_coff, &d_clen, &d_perm, &d_match, &d_ra, &d_la,
                                                                                          &d_next, &d_ov, &d_heads, &d_nch, &d_need}};
+    AsmLap lap;
     std::vector<u64> coff(n + 1, 0);
     std::vector<u32> clen(n);
     std::string cat;
@@ -174,32 +228,78 @@ int assemble_signatures_device(gasm_ctx* ctx, const std::vector<std::string>& co
     HIPCHK(hipMemcpyAsync(nch.data(), d_nch.p, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(need.data(), d_need.p, rows, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    lap(ctx, "merge: uploads + kernels + results");
     if (herr) { gasm_set_error("contigs contain a base outside upper-case ACGT"); return GASM_ERR_NON_ACGT; }
-    // ---- chains -> signatures (u32 contig, u32 overlap, u32 contig, ...); rows the kernel handed back go to the host merge
-    std::vector<std::string> all;
+    // ---- chains -> signatures (u32 contig, u32 overlap, u32 contig, ...); rows the kernel handed back go to the host merge.
+    // Threads over the rows; every signature comes with a 64-bit hash, and the distinct ones are found by sorting the hashes
+    // (equal hashes are compared in full: a collision costs a comparison, never a scaffold).  The order of `sigs` is of no
+    // consequence: the scaffolds are ordered as strings on the device.
     std::vector<u32> redo;
-    std::string sig;
-    for (u64 r = 0; r < rows; ++r) {
-        if (need[r]) { redo.insert(redo.end(), perm + r * n, perm + (r + 1) * n); continue; }
-        for (u32 q = 0; q < nch[r]; ++q) {
-            sig.clear();
-            for (u32 x = heads[r * n + q];; x = next[r * n + x]) {
-                sig.append(reinterpret_cast<const char*>(&x), 4);
-                if (next[r * n + x] == GASM_NONE32) break;
-                const u32 o = ov[r * n + x];
-                sig.append(reinterpret_cast<const char*>(&o), 4);
+    for (u64 r = 0; r < rows; ++r) if (need[r]) redo.insert(redo.end(), perm + r * n, perm + (r + 1) * n);
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = std::max(1u, std::min(nt, 16u));
+    if (rows < 256) nt = 1;
+    struct Part { std::vector<std::string> sig; std::vector<u64> hash; };
+    std::vector<Part> parts(nt);
+    auto work = [&](unsigned t) {
+        Part& P = parts[t];
+        std::string sig;
+        const u64 r0 = rows * t / nt, r1 = rows * (t + 1) / nt;
+        for (u64 r = r0; r < r1; ++r) {
+            if (need[r]) continue;
+            for (u32 q = 0; q < nch[r]; ++q) {
+                sig.clear();
+                u64 h = 0xCBF29CE484222325ull;
+                for (u32 x = heads[r * n + q];; x = next[r * n + x]) {
+                    sig.append(reinterpret_cast<const char*>(&x), 4);
+                    h = (h ^ x) * 0x100000001B3ull;
+                    if (next[r * n + x] == GASM_NONE32) break;
+                    const u32 o = ov[r * n + x];
+                    sig.append(reinterpret_cast<const char*>(&o), 4);
+                    h = (h ^ (0x9E3779B9ull + o)) * 0x100000001B3ull;
+                }
+                P.sig.push_back(sig);
+                P.hash.push_back(h ^ (h >> 29));
             }
-            all.push_back(sig);
         }
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto& t : th) t.join();
     }
+    std::vector<std::string> all;
     if (!redo.empty()) {
-        std::vector<std::string> hs;
-        if (!gasm_host::assemble_signatures(contigs, redo.data(), redo.size() / n, n, k, hs)) return GASM_OK;      // (cannot happen: same preconditions)
-        all.insert(all.end(), hs.begin(), hs.end());
+        if (!gasm_host::assemble_signatures(contigs, redo.data(), redo.size() / n, n, k, all)) return GASM_OK;      // (cannot happen: same preconditions)
         if (rows_on_host) *rows_on_host = redo.size() / n;
     }
-    std::sort(all.begin(), all.end());
-    all.erase(std::unique(all.begin(), all.end()), all.end());
+    lap(ctx, "merge: signatures (host threads)");
+    {
+        struct Ref { u64 h; u32 part, i; };
+        std::vector<Ref> refs;
+        size_t total = 0;
+        for (const Part& P : parts) total += P.sig.size();
+        refs.reserve(total);
+        for (u32 t = 0; t < nt; ++t) for (u32 i = 0; i < parts[t].sig.size(); ++i) refs.push_back(Ref{parts[t].hash[i], t, i});
+        std::sort(refs.begin(), refs.end(), [](const Ref& a, const Ref& b) { return a.h < b.h; });
+        const size_t host_sigs = all.size();
+        for (size_t a = 0; a < refs.size();) {
+            size_t b = a + 1;
+            while (b < refs.size() && refs[b].h == refs[a].h) ++b;
+            // the distinct strings among refs[a, b) (one, unless two signatures share a hash)
+            const size_t first_kept = all.size();
+            for (size_t x = a; x < b; ++x) {
+                std::string& sx = parts[refs[x].part].sig[refs[x].i];
+                bool seen = false;
+                for (size_t y = first_kept; y < all.size() && !seen; ++y) seen = all[y] == sx;       // (against the group's distinct strings only: a popular chain comes 10 000 times)
+                if (!seen) all.push_back(std::move(sx));
+            }
+            a = b;
+        }
+        if (host_sigs) { std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end()); }      // (rows merged on the host may repeat a chain)
+    }
+    lap(ctx, "merge: distinct signatures");
     sigs.swap(all);
     *used = true;
     return GASM_OK;
