@@ -1081,8 +1081,8 @@ int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 ta
     if (st == GASM_OK && hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
     if (st == GASM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
     if (st != GASM_OK || herr) { ascii.release(); err.release(); twords.release(); return st; }   // not ACGT: host routine
-    // one wave per path, at most 16 waves per CU resident-ish; every wave parks one byte per target column
-    const u32 waves = std::min<u32>(P, (u32)ctx->n_cu * 16u);
+    // one wave per path, 32 waves per CU (58 VGPRs: eight per SIMD; 16 -> 32 took 3 % off: the kernel is VALU-bound); every wave parks one byte per target column
+    const u32 waves = std::min<u32>(P, (u32)ctx->n_cu * (getenv("GASM_LEV_WAVES") ? (u32)atoi(getenv("GASM_LEV_WAVES")) : 32u));
     const u32 wgs = (waves + GASM_WG / 64 - 1) / (GASM_WG / 64);
     const u64 stride = (target_len + 64 + 63) & ~(u64)63;
     st = carry.ensure((size_t)wgs * (GASM_WG / 64) * stride);
