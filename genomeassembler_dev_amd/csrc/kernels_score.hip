@@ -146,12 +146,19 @@ __global__ void __launch_bounds__(GASM_WG) k_first_to_poscnt(const u32* __restri
 // Batch path: the paths are the contigs of the same build, so the index already exists.  A read of length >= k starts
 // with a k-mer; that k-mer is one distinct edge (bucket, bin, a one-or-two-key search); list ranking left (head,
 // distance) on every edge, i.e. the contig and the offset of the k-mer inside it.  Every k-mer lies on at most one
-// contig, once, so this is the only place the read can occur: compare the rest of the read there
-// (lib/DeNovoAssembler.cpp:360).
+// contig, once, so this is the only place the read can occur (lib/DeNovoAssembler.cpp:360).
+// Round 3: the rest of the read is NOT compared there any more.  The graph was built from these very reads, so every k-mer of
+// the read is an edge and consecutive k-mers are consecutive edges; inside a contig every node between two edges has exactly one
+// out-edge (that is what ends a contig: lib/DeNovoAssembler.cpp:161-189), so a walk that enters the contig at edge d is forced
+// along it — if the read fits between d and the contig's end it IS the contig's text there, and if it does not fit it crosses
+// a branching node and occurs in no contig.  The comparison was six of the scorer's ~twelve scattered requests per read
+// (k_score_reads_graph 0.064 -> see DESIGN.md §4); `verify` != 0 (GASM_SCORE_VERIFY=1) still makes it, and a mismatch then raises
+// bit 2 of the build's flags — the argument above checked against the data.
 // Returns the global base position of the hit, or ~0 when the read matches no contig.
 template <class K>
 __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& gv, const u64* __restrict__ link,
-                                           const u32* __restrict__ e_cid, const PathSet& ps, u32 seg, u64 r, u32* path, u64* pbeg, u64* pend) {
+                                           const u32* __restrict__ e_cid, const PathSet& ps, u32 seg, u64 r, u32* path, u64* pbeg, u64* pend,
+                                           int verify, u32* __restrict__ verify_flag) {
     u64 p0; u32 len;
     read_span(rs, r, &p0, &len);
     if (len < (u32)gv.k) return ~0ull;
@@ -168,9 +175,11 @@ __device__ __forceinline__ u64 graph_match(const ReadSet& rs, const GraphView& g
     *pbeg = po.x; *pend = po.y;
     const u64 g = po.x + ((u32)l & 0x7FFFFFFFu);
     if (g + len > po.y) return ~0ull;
-    // (128 bases per round, aligned in registers: word-by-word with an early exit was a chain of dependent round trips)
-    const bool same = bases_equal(rs.words, p0, ps.words, g, len);
-    return same ? g : ~0ull;
+    if (verify) {
+        // (128 bases per round, aligned in registers: word-by-word with an early exit was a chain of dependent round trips)
+        if (!bases_equal(rs.words, p0, ps.words, g, len)) { atomicOr(verify_flag, 1u); return ~0ull; }
+    }
+    return g;
 }
 
 // Batch scoring without position counters.  bp_score of a path = sum over the reads that occur in it of
@@ -184,7 +193,8 @@ template <class K>
 __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, GraphView gv, const u64* __restrict__ link,
                                                                const u32* __restrict__ e_cid, PathSet ps,
                                                                const long long* __restrict__ dfix, int kmer, u32 reads_per_wg, u32 chunks,
-                                                               u32 lds_paths, u32* __restrict__ cnt, unsigned long long* __restrict__ sum) {
+                                                               u32 lds_paths, u32* __restrict__ cnt, unsigned long long* __restrict__ sum, int verify,
+                                                               u32* __restrict__ verify_flag) {
     // accumulators of the segment's paths: `lds_paths` (<= GASM_SCORE_PATH_CAP) of each, sized by the launch — a fixed
     // 72 KB would leave two workgroups per CU, and this kernel is a chain of dependent gathers that lives on occupancy
     extern __shared__ unsigned long long s_sum[];
@@ -202,7 +212,7 @@ __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, Graph
     for (u64 r = r0 + threadIdx.x; r < r1; r += GASM_WG) {
         u32 c = 0;
         u64 pb = 0, pe = 0;
-        const u64 g = graph_match<K>(rs, gv, link, e_cid, ps, seg, r, &c, &pb, &pe);
+        const u64 g = graph_match<K>(rs, gv, link, e_cid, ps, seg, r, &c, &pb, &pe, verify, verify_flag);
         if (g == ~0ull) continue;
         const u32 plen = (u32)(pe - pb);
         u32 idx;
@@ -219,9 +229,9 @@ __global__ void __launch_bounds__(GASM_WG) k_score_reads_graph(ReadSet rs, Graph
 }
 
 template __global__ void k_score_reads_graph<u64>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32, u32, u32*,
-                                                  unsigned long long*);
+                                                  unsigned long long*, int, u32*);
 template __global__ void k_score_reads_graph<K128>(ReadSet, GraphView, const u64*, const u32*, PathSet, const long long*, int, u32, u32, u32, u32*,
-                                                   unsigned long long*);
+                                                   unsigned long long*, int, u32*);
 
 // The batch scorer's accumulators, cleared for the paths there are (*n_paths_p lives on the device: the contigs of a build
 // the host has not waited for; a memset would have to cover the upper bound).

@@ -126,6 +126,7 @@ struct ScoreState {
     size_t stride = 1;                      // entries per output array on the device (paths + 1, or their upper bound + 1)
     const BuildState* graph = nullptr;      // batch scoring of a build's own contigs: the number of paths comes with its report
     bool want_freq = false, want_pd = false, launched = false;
+    bool verify = false;                    // the graph scorer compared every read with its contig (GASM_SCORE_VERIFY)
     std::vector<double> h_bp, h_nf, h_nl, h_freq, h_pd;
     std::vector<int32_t> h_breaks, h_len;
     std::vector<u64> h_pd_off;

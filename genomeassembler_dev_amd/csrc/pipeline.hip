@@ -1202,6 +1202,10 @@ static int score_launch_graph(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kme
     u64 max_reads = 0;
     for (u32 s = 0; s < S; ++s) max_reads = std::max(max_reads, rd.h_seg_read_off[s + 1] - rd.h_seg_read_off[s]);
     GCHK(const_cast<ScoreTable&>(tb).set_fixed(ctx, max_reads));
+    // GASM_SCORE_VERIFY=1: compare every read with the contig text where the graph says it lies (kernels_score.hip, graph_match);
+    // a mismatch raises flags[2] of the build and pipeline_score_fetch refuses the scores
+    const int verify = env_int("GASM_SCORE_VERIFY", 0);
+    ss.verify = verify != 0;
     const u32 reads_per_wg = 256;     // one read per thread: the match is a chain of dependent loads
     const u32 rchunks = (u32)ceil_div_u64(max_reads, reads_per_wg);
     // per-path accumulators kept in LDS: sized from the last build of these reads (a segment with more paths than that
@@ -1210,11 +1214,11 @@ static int score_launch_graph(gasm_ctx* ctx, DevReads& rd, DevPaths& dp, int kme
     if (graph.words == 1) {
         GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<u64>, seg_grid(rchunks, S), dim3(GASM_WG), (size_t)lds_paths * 12, rd.view(),
                 gv, graph.d_link.as<u64>(), graph.d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, lds_paths, ss.d_total.as<u32>(),
-                d_fx);
+                d_fx, verify, graph.d_flags.as<u32>() + 2);
     } else {
         GLAUNCH(ctx, "k_score_reads_graph", k_score_reads_graph<K128>, seg_grid(rchunks, S), dim3(GASM_WG), (size_t)lds_paths * 12, rd.view(),
                 gv, graph.d_link.as<u64>(), graph.d_ecid.as<u32>(), ps, tb.d_fix.as<long long>(), kmer, reads_per_wg, rchunks, lds_paths, ss.d_total.as<u32>(),
-                d_fx);
+                d_fx, verify, graph.d_flags.as<u32>() + 2);
     }
     double* o_bp = ss.d_out_f64.as<double>();
     double* o_nf = o_bp + PC;
@@ -1370,6 +1374,12 @@ int pipeline_score_fetch(gasm_ctx* ctx, ScoreState& ss) {
     if (ss.graph) {
         if (ss.graph->pending) { gasm_set_error("scores fetched before the build's report was read"); return GASM_ERR_STATE; }
         ss.n_paths = ss.graph->n_contigs;
+        if (ss.verify) {
+            u32 bad = 0;
+            HIPCHK(hipMemcpyAsync(&bad, ss.graph->d_flags.as<u32>() + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            if (bad) { gasm_set_error("GASM_SCORE_VERIFY: a read that fits its contig by the graph differs from the contig's text"); return GASM_ERR_STATE; }
+        }
     }
     const u32 P = ss.n_paths;
     double* o_bp = ss.d_out_f64.as<double>();

@@ -851,6 +851,34 @@ def test_guided_traversal_against_own_restatement(qtable):
         b.close()
 
 
+def test_graph_scorer_needs_no_base_comparison(qtable, monkeypatch):
+    """The batch scorer takes a read's place from the graph (first k-mer -> edge -> contig, offset) and, since round 3, does not
+    compare the rest of the read with the contig: inside a contig every walk is forced, so a read that fits IS the text there.
+    GASM_SCORE_VERIFY=1 makes the comparison again and refuses the scores on any mismatch: both ways must give the same numbers
+    (and the oracle's) — planted repeats, reads that cross branching nodes, 64- and 128-bit keys, ragged lengths."""
+    keys, prob = qtable
+    for k, rl, n_seg, L in ((21, 60, 4, 9000), (41, 100, 3, 8000)):
+        reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, 25, seed0=9800 + k, planted=True)
+        out = []
+        for verify in ("0", "1"):
+            monkeypatch.setenv("GASM_SCORE_VERIFY", verify)
+            b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+            b.build(k, genome_len_hint=L).score(8, prob)
+            out.append((b.contigs(), b.scores()))
+            b.close()
+        (c0, s0), (c1, s1) = out
+        assert c0 == c1
+        for kk in ("kmer_breaks", "sequence_len", "bp_score", "bp_score_norm_by_break_freqs", "bp_score_norm_by_len"):
+            assert np.array_equal(s0[kk], s1[kk]), (k, kk)
+        assert int(s0["kmer_breaks"].sum()) < int(seg_off[-1])          # some reads cross a branching node and occur in no contig
+        for s in range(n_seg):
+            rs = _strs(reads[int(seg_off[s]):int(seg_off[s + 1])])
+            o = orc.calc_breakscore(c0[s], rs, "", 8, keys, prob, with_lev=False, with_freq=False)
+            a, e = int(s0["seg_contig_off"][s]), int(s0["seg_contig_off"][s + 1])
+            assert s0["kmer_breaks"][a:e].tolist() == o["kmer_breaks"].tolist(), (k, s)
+            assert np.abs(s0["bp_score"][a:e] - o["bp_score"]).max(initial=0.0) < TOL
+
+
 @pytest.mark.timeout(900)
 def test_guided_traversal_at_configs4_size(qtable):
     """Row A16 at the size BASELINE configs[4] names: 50 kb segments, 250 bp reads at 100x, k = 51 (128-bit keys) — two
