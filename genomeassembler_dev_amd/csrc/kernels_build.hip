@@ -748,6 +748,7 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
     constexpr int KPL = NLD * 16 / sizeof(K);    // keys per thread and iteration
     const u64 nch = n * sizeof(K) / 16;          // 16-byte chunks in the bucket
     const uint4* src = reinterpret_cast<const uint4*>(keys + beg);
+    if (dbg & 16) src = reinterpret_cast<const uint4*>(keys + bstart[bucket & 7u]);      // ablation: every workgroup streams one of eight buckets (L2-resident): the table work without HBM
     // the loads of the next iteration are issued before this iteration's keys go into the table, so the table work
     // (LDS latency) and the HBM latency overlap inside every wave
     uint4 v[NLD];
