@@ -56,7 +56,18 @@ struct SubBatch {
     bool paths_ready = false, table_set = false;
     hipEvent_t ev_streamed = nullptr;
     GuidedState guided;
+    // Scoring on a stream of its own (round 3; one-block batches): the graph-indexed scoring of step n only reads what build n
+    // left behind and what the NEXT build does not touch before its de-duplication (which rewrites the directories the scorer
+    // searches) — so it runs on a lane beside the next build's partition instead of in front of it.  ev_built: the build is
+    // queued in full (the scorer's lane waits for it); ev_scored: the scoring is done (the next de-duplication waits for it).
+    gasm_ctx* scx = nullptr;                // the lane
+    gasm_ctx* score_cx_last = nullptr;      // where the last scoring was queued (fetches read from there)
+    hipEvent_t ev_built = nullptr, ev_scored = nullptr;
 };
+
+static bool score_lane_wanted(const gasm_batch* b);
+// the lane and its events, on first use; false: no lane (more than one block, switched off, or no resources)
+static bool score_lane(gasm_batch* b, SubBatch& sb);
 
 struct gasm_batch {
     gasm_ctx* ctx = nullptr;
@@ -93,13 +104,18 @@ static int sub_finish(gasm_batch* b, SubBatch& sb) {
             GCHK(pipeline_contig_paths(sb.cx, sb.rd, sb.bs, sb.dp));
             sb.paths_ready = true;
             pipeline_contig_paths_host(sb.rd, sb.bs, sb.dp);
+            if (sb.scx) HIPCHK(hipStreamSynchronize(sb.scx->stream));      // (the first attempt's scoring: its buffers are reused)
             GCHK(pipeline_score_launch(sb.cx, sb.rd, sb.dp, b->score_kmer, sb.tb, false, false, sb.ss, &sb.bs));
+            sb.score_cx_last = sb.cx;
         }
     }
     return GASM_OK;
 }
 static int batch_finish(gasm_batch* b) {
-    for (SubBatch& sb : b->sub) GCHK(sub_finish(b, sb));
+    for (SubBatch& sb : b->sub) {
+        GCHK(sub_finish(b, sb));
+        if (sb.scx) HIPCHK(hipStreamSynchronize(sb.scx->stream));      // whatever the lane still scores: results are asked for
+    }
     return GASM_OK;
 }
 
@@ -112,6 +128,21 @@ static int batch_finish(gasm_batch* b) {
         gasm_set_error("internal error: %s", e.what());                        \
         return GASM_ERR_INVALID;                                               \
     }
+
+static bool score_lane_wanted(const gasm_batch* b) {
+    const char* v = getenv("GASM_SCORE_LANE");
+    return b->sub.size() == 1 && !(v && *v == '0');
+}
+static bool score_lane(gasm_batch* b, SubBatch& sb) {
+    if (!score_lane_wanted(b)) return false;
+    if (sb.scx && sb.ev_built && sb.ev_scored) return true;
+    if (hipSetDevice(sb.cx->device) != hipSuccess) return false;
+    if (!sb.scx) sb.scx = sb.cx->lane(0);
+    if (!sb.scx) return false;
+    if (!sb.ev_built && hipEventCreateWithFlags(&sb.ev_built, hipEventDisableTiming) != hipSuccess) { sb.ev_built = nullptr; return false; }
+    if (!sb.ev_scored && hipEventCreateWithFlags(&sb.ev_scored, hipEventDisableTiming) != hipSuccess) { sb.ev_scored = nullptr; return false; }
+    return true;
+}
 
 static void strlist_from(const std::vector<std::string>& v, std::vector<char>& data, std::vector<u64>& off) {
     off.assign(v.size() + 1, 0);
@@ -704,6 +735,9 @@ void gasm_batch_free(gasm_batch* b) {
     b->d_read_start.release();
     for (SubBatch& sb : b->sub) {
         if (sb.cx) { (void)hipSetDevice(sb.cx->device); (void)hipStreamSynchronize(sb.cx->stream); }
+        if (sb.scx) (void)hipStreamSynchronize(sb.scx->stream);
+        if (sb.ev_built) (void)hipEventDestroy(sb.ev_built);
+        if (sb.ev_scored) (void)hipEventDestroy(sb.ev_scored);
         sb.rd.release(); sb.bs.release(); sb.dp.release(); sb.tb.release(); sb.ss.release(); sb.guided.release();
         if (sb.ev_streamed) (void)hipEventDestroy(sb.ev_streamed);
     }
@@ -716,7 +750,10 @@ int gasm_batch_build(gasm_batch* b, int k, uint64_t genome_len_hint) {
     b->built = false; b->scored = false;
     for (SubBatch& sb : b->sub) {
         sb.paths_ready = false; sb.ss.valid = false; sb.ss.launched = false;
+        const bool lane = score_lane(b, sb);
+        sb.bs.ev_before_dedup = lane ? sb.ev_scored : nullptr;      // the last step's scoring still searches the directories this build's de-duplication rewrites
         GCHK(pipeline_build(sb.cx, sb.rd, k, genome_len_hint, sb.bs));
+        if (lane) HIPCHK(hipEventRecord(sb.ev_built, sb.cx->stream));
     }
     b->built = true;
     return GASM_OK;
@@ -740,12 +777,18 @@ int gasm_batch_score(gasm_batch* b, int kmer, const double* table) {
         // reads shorter than k (or none): the general scorer, which sizes its tables on the host — after the build's report
         const bool through_graph = pipeline_score_uses_graph(sb.rd, sb.bs);
         if (!through_graph) GCHK(sub_finish(b, sb));
+        // through the graph: on the lane, behind the build (its queue, not its completion: stream order does the rest)
+        gasm_ctx* const cx = (through_graph && sb.scx && sb.ev_built && !getenv("GASM_SCORE_VERIFY")) ? sb.scx : sb.cx;
+        if (cx != sb.cx) HIPCHK(hipStreamWaitEvent(cx->stream, sb.ev_built, 0));
+        else if (sb.scx) HIPCHK(hipStreamSynchronize(sb.scx->stream));
         if (!sb.paths_ready) {
-            GCHK(pipeline_contig_paths(sb.cx, sb.rd, sb.bs, sb.dp));
+            GCHK(pipeline_contig_paths(cx, sb.rd, sb.bs, sb.dp));
             sb.paths_ready = true;
         }
         if (!through_graph) pipeline_contig_paths_host(sb.rd, sb.bs, sb.dp);
-        GCHK(pipeline_score_launch(sb.cx, sb.rd, sb.dp, kmer, sb.tb, false, false, sb.ss, &sb.bs));
+        GCHK(pipeline_score_launch(cx, sb.rd, sb.dp, kmer, sb.tb, false, false, sb.ss, &sb.bs));
+        sb.score_cx_last = cx;
+        if (sb.ev_scored) HIPCHK(hipEventRecord(sb.ev_scored, cx->stream));
     }
     b->scored = true;
     b->score_kmer = kmer;
@@ -761,7 +804,7 @@ int gasm_batch_guided(gasm_batch* b) {
     if (b->sub.size() != 1) { gasm_set_error("gasm_batch_guided: batches split into sub-batches are not supported"); return GASM_ERR_STATE; }
     GCHK(batch_finish(b));
     SubBatch& sb = b->sub[0];
-    GCHK(pipeline_score_fetch(sb.cx, sb.ss));
+    GCHK(pipeline_score_fetch(sb.score_cx_last ? sb.score_cx_last : sb.cx, sb.ss));
     return guided_build(sb.cx, sb.rd, sb.bs, sb.dp, sb.ss, sb.tb, b->score_kmer, sb.guided);
     API_GUARD_END
 }
@@ -887,7 +930,7 @@ int gasm_batch_fetch_scores(gasm_batch* b, const double** bp_score, const double
     API_GUARD_BEGIN
     if (!b || !bp_score || !norm_by_break_freqs || !norm_by_len || !kmer_breaks || !sequence_len) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     GCHK(batch_finish(b));
-    for (SubBatch& sb : b->sub) GCHK(pipeline_score_fetch(sb.cx, sb.ss));
+    for (SubBatch& sb : b->sub) GCHK(pipeline_score_fetch(sb.score_cx_last ? sb.score_cx_last : sb.cx, sb.ss));
     if (b->sub.size() == 1) {
         ScoreState& ss = b->sub[0].ss;
         *bp_score = ss.h_bp.data(); *norm_by_break_freqs = ss.h_nf.data(); *norm_by_len = ss.h_nl.data();

@@ -81,6 +81,7 @@ struct BuildState {
     // ---- optional stream choreography of sub-batches (capi.hip): wait for this event before the first kernel, record
     // that one once the streaming kernels (partition + de-duplication) are queued
     hipEvent_t ev_wait = nullptr, ev_streamed = nullptr;
+    hipEvent_t ev_before_dedup = nullptr;   // waited for between the partition and the de-duplication (the last step's scoring on its lane: capi.hip)
     // ---- report: written by the last kernels of a build into pinned memory, read by pipeline_build_finish
     u32* h_report = nullptr;
     size_t h_report_words = 0;

@@ -584,6 +584,8 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
                     bs.d_bstart.as<u64>(), bs.d_toff.as<u32>(), bs.d_tcnt.as<ushort4>(), bs.d_keys.as<K128>(), n_alloc);
         }
     }
+    // (what still reads the directories and dense arrays the de-duplication and everything behind it rewrite)
+    if (bs.ev_before_dedup) HIPCHK(hipStreamWaitEvent(ctx->stream, bs.ev_before_dedup, 0));
     unsigned long long* d_stamps = nullptr;
     static DBuf stamp_buf;
     if (knobs().stamps) {   // diagnostic: per-phase cycle totals of k_bucket_dedup to stderr
