@@ -60,6 +60,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--alone-steps", type=int, default=10, help="untimed extra steps with ONE step in flight, for the kernels' own durations (0 = skip)")
     ap.add_argument("--steps", type=int, default=100)      # (a step is ~1 ms: 20 of them were over before the clocks had settled)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
@@ -218,14 +219,28 @@ def main():
         def step():
             batch.build(k, genome_len_hint=L)
             batch.score(8, table)
-        # one untimed build whose report is read before anything is timed: a batch whose buckets outgrow the single-pass
-        # partition's regions (or its tables) settles on the configuration that works here, not inside the timed steps
-        step()
-        batch.distinct()
+        # untimed builds whose reports are read before anything is timed: a batch whose buckets outgrow the single-pass
+        # partition's regions (or its tables) settles on the configuration that works here, not inside the timed steps (four:
+        # consecutive steps of a one-block batch take its step slots in turn, up to four of them)
+        for _ in range(4):
+            step()
+            batch.distinct()
         dt, prof = timed(step, args.steps, args.warmup, profile=profiled)
         seg, keys, mult, _w = batch.distinct()
         n_distinct = int(seg[-1])
         sc_all = batch.scores()
+        # Consecutive steps of a one-block batch are in flight together (step slots, capi.hip): inside the timed region a
+        # kernel shares the chip with the other steps' kernels and its launch duration says how long it was resident, not
+        # what it moves per second when it has the chip.  A short untimed pass with one step in flight (GASM_PINGPONG=0,
+        # read by every gasm_batch_build) gives the kernels' own durations; both go into `roofline`.
+        prof_alone = dt_alone = None
+        if args.alone_steps > 0 and os.environ.get("GASM_PINGPONG", "1") != "0" and nseg > 0:
+            keep = os.environ.get("GASM_SCORE_LANE")
+            os.environ["GASM_PINGPONG"] = os.environ["GASM_SCORE_LANE"] = "0"       # (nor the last step's scoring beside the partition)
+            dt_alone, prof_alone = timed(step, args.alone_steps, 3, profile=profiled)
+            del os.environ["GASM_PINGPONG"], os.environ["GASM_SCORE_LANE"]
+            if keep is not None:
+                os.environ["GASM_SCORE_LANE"] = keep
         # a second upload, timed warm (the first one pays the allocations): what a caller that hands over host buffers sees
         t_up2 = time.perf_counter()
         b2 = ga.SegmentBatch.from_packed(words, seg_off, fixed_len=rl, ctx=ctx)
@@ -278,6 +293,15 @@ def main():
                                   "achieved_GBs": round(alg_bytes[n] / (prof[n][0] / prof[n][1] / 1e3) / 1e9, 1)}
                               for n in dominant if n != dom and n in prof and prof[n][1]}}
 
+    if roofline and args.mode == "segments":
+        roofline["steps_in_flight"] = "consecutive steps of a one-block batch overlap (step slots): durations above are residence times on a shared chip"
+        if prof_alone and prof_alone.get(dom, (0.0, 0))[1]:
+            a_ms = {n: prof_alone[n][0] / prof_alone[n][1] for n in dominant if n in prof_alone and prof_alone[n][1]}
+            roofline["one_step_in_flight"] = {
+                "steps": args.alone_steps, "ms_per_step": round(dt_alone / args.alone_steps * 1e3, 4), "kernel": dom,
+                "avg_launch_ms": round(a_ms[dom], 4), "achieved": round(alg_bytes[dom] / (a_ms[dom] / 1e3) / 1e9, 1),
+                "frac": round(alg_bytes[dom] / (a_ms[dom] / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                "other": {n: {"avg_launch_ms": round(v, 4), "achieved_GBs": round(alg_bytes[n] / (v / 1e3) / 1e9, 1)} for n, v in a_ms.items() if n != dom}}
     if roofline and score_bytes and prof.get("k_score_reads_graph", (0.0, 0))[1]:
         # (low by construction: the scorer's work is index look-ups and compares, not bytes)
         sms = prof["k_score_reads_graph"][0] / prof["k_score_reads_graph"][1]

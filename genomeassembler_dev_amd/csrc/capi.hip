@@ -45,24 +45,54 @@ struct gasm_scores {
 // results; it lets the latency-bound graph phase of one block run under the bandwidth-bound partition/de-duplication
 // phase of the next: block j's first kernel waits (stream event) until block j-1's streaming kernels are queued, and
 // with builds queued ahead of their reports the blocks of consecutive steps interleave the same way.
+// What one step (build + scoring) of a block owns: the graph, the contigs as paths, the scores — and the stream it runs on.
+struct StepSlot {
+    gasm_ctx* cx = nullptr;
+    hipEvent_t ev_streamed = nullptr;       // its build's streaming kernels (partition, de-duplication) are done
+    BuildState bs;
+    DevPaths dp;
+    ScoreState ss;
+    bool paths_ready = false;
+};
+
 struct SubBatch {
     gasm_ctx* cx = nullptr;                 // the lane it runs on (lane 0 = the batch's context itself)
     u32 seg0 = 0, seg1 = 0;                 // its block of the batch's segments
     DevReads rd;
-    BuildState bs;
-    DevPaths dp;
     ScoreTable tb;
-    ScoreState ss;
-    bool paths_ready = false, table_set = false;
+    bool table_set = false;
     hipEvent_t ev_streamed = nullptr;
     GuidedState guided;
-    // Scoring on a stream of its own (round 3; one-block batches): the graph-indexed scoring of step n only reads what build n
-    // left behind and what the NEXT build does not touch before its de-duplication (which rewrites the directories the scorer
-    // searches) — so it runs on a lane beside the next build's partition instead of in front of it.  ev_built: the build is
-    // queued in full (the scorer's lane waits for it); ev_scored: the scoring is done (the next de-duplication waits for it).
+    // Two step slots, taken in turn (round 3; one-block batches, GASM_PINGPONG=0 switches it off): consecutive steps of a
+    // resident pipeline are independent of each other — same reads, own graph, own scores — so step n + 1 is queued on the
+    // other slot's stream with the other slot's buffers and its streaming kernels (partition, de-duplication: HBM and LDS)
+    // run beside step n's graph and scoring kernels (latency-bound, a few waves per CU).  Results are always those of the
+    // slot the last gasm_batch_build took.
+    StepSlot slot[4];
+    int cur = 0, n_slots = 2;
+    bool pingpong = false;
+    // GASM_PINGPONG=1 (default): whole steps on equal streams, GASM_STEP_SLOTS of them (2..4, default 3).
+    // GASM_PINGPONG=2: every step's streaming kernels on the block's own stream, back to back, and each slot's graph, contigs
+    // and scoring on a tail lane of its own, whose stream the dispatcher serves first.  Measured: the
+    // persistent streaming workgroups hold the CUs' LDS, the small kernels beside them run several times slower, and the
+    // next-but-one partition waits for them — 0.92-0.98 ms/step against 0.88 with equal streams.
+    int pp_mode = 1;
+    StepSlot& S() {
+        StepSlot& x = slot[cur];
+        if (!x.cx && pingpong && pp_mode == 2) x.cx = cx->tail_lane(cur);
+        if (!x.cx) x.cx = cur ? cx->lane((size_t)cur) : cx;
+        if (!x.cx) x.cx = cx;                // (no second stream to be had: both slots on the block's own)
+        return x;
+    }
+    const StepSlot& S() const { return slot[cur]; }
+    // Scoring on a stream of its own (one-block batches without ping-pong): the graph-indexed scoring of step n only reads what
+    // build n left behind and what the NEXT build does not touch before its de-duplication (which rewrites the directories the
+    // scorer searches) — so it runs on a lane beside the next build's partition instead of in front of it.  ev_built: the build
+    // is queued in full (the scorer's lane waits for it); ev_scored: the scoring is done (the next de-duplication waits for it).
     gasm_ctx* scx = nullptr;                // the lane
     gasm_ctx* score_cx_last = nullptr;      // where the last scoring was queued (fetches read from there)
     hipEvent_t ev_built = nullptr, ev_scored = nullptr;
+    bool lane_last = false;                 // the last build recorded ev_built for the lane (GASM_SCORE_LANE is read per build)
 };
 
 static bool score_lane_wanted(const gasm_batch* b);
@@ -80,6 +110,7 @@ struct gasm_batch {
     // the last gasm_batch_score, kept to queue it again behind a build that had to be repeated
     bool scored = false;
     int score_kmer = 0;
+    int last_k = 0;                         // k of the last gasm_batch_build
     // concatenated host results of the sub-batches (fetch)
     std::vector<u64> h_seg_doff, h_dk_key, h_seg_coff, h_c_off;
     std::vector<u32> h_dk_cnt, h_nxt;
@@ -97,16 +128,16 @@ struct gasm_batch {
 // Read the report of a sub-batch's queued build (repeating the build if it failed, and then the scoring queued behind it).
 static int sub_finish(gasm_batch* b, SubBatch& sb) {
     bool rebuilt = false;
-    GCHK(pipeline_build_finish(sb.cx, sb.rd, sb.bs, &rebuilt));
+    GCHK(pipeline_build_finish(sb.S().cx, sb.rd, sb.S().bs, &rebuilt));
     if (rebuilt) {
-        sb.paths_ready = false;
+        sb.S().paths_ready = false;
         if (b->scored) {
-            GCHK(pipeline_contig_paths(sb.cx, sb.rd, sb.bs, sb.dp));
-            sb.paths_ready = true;
-            pipeline_contig_paths_host(sb.rd, sb.bs, sb.dp);
+            GCHK(pipeline_contig_paths(sb.S().cx, sb.rd, sb.S().bs, sb.S().dp));
+            sb.S().paths_ready = true;
+            pipeline_contig_paths_host(sb.rd, sb.S().bs, sb.S().dp);
             if (sb.scx) HIPCHK(hipStreamSynchronize(sb.scx->stream));      // (the first attempt's scoring: its buffers are reused)
-            GCHK(pipeline_score_launch(sb.cx, sb.rd, sb.dp, b->score_kmer, sb.tb, false, false, sb.ss, &sb.bs));
-            sb.score_cx_last = sb.cx;
+            GCHK(pipeline_score_launch(sb.S().cx, sb.rd, sb.S().dp, b->score_kmer, sb.tb, false, false, sb.S().ss, &sb.S().bs));
+            sb.score_cx_last = sb.S().cx;
         }
     }
     return GASM_OK;
@@ -129,6 +160,11 @@ static int batch_finish(gasm_batch* b) {
         return GASM_ERR_INVALID;                                               \
     }
 
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static bool env_flag(const char* name, bool dflt) {
+    const char* v = getenv(name);
+    return v && *v ? *v != '0' : dflt;
+}
 static bool score_lane_wanted(const gasm_batch* b) {
     const char* v = getenv("GASM_SCORE_LANE");
     return b->sub.size() == 1 && !(v && *v == '0');
@@ -579,8 +615,8 @@ int gasm_batch_create(gasm_ctx* ctx, const char* reads, const uint64_t* read_off
     }
     if (st != GASM_OK) { gasm_batch_free(b); return st; }
     for (u32 j = 0; j < nsub; ++j) {
-        b->sub[j].bs.ev_streamed = b->sub[j].ev_streamed;
-        b->sub[j].bs.ev_wait = j ? b->sub[j - 1].ev_streamed : nullptr;
+        b->sub[j].slot[0].bs.ev_streamed = b->sub[j].ev_streamed;
+        b->sub[j].slot[0].bs.ev_wait = j ? b->sub[j - 1].ev_streamed : nullptr;
     }
     *out = b;
     return GASM_OK;
@@ -738,7 +774,8 @@ void gasm_batch_free(gasm_batch* b) {
         if (sb.scx) (void)hipStreamSynchronize(sb.scx->stream);
         if (sb.ev_built) (void)hipEventDestroy(sb.ev_built);
         if (sb.ev_scored) (void)hipEventDestroy(sb.ev_scored);
-        sb.rd.release(); sb.bs.release(); sb.dp.release(); sb.tb.release(); sb.ss.release(); sb.guided.release();
+        for (StepSlot& x : sb.slot) { if (x.cx && x.cx != sb.cx) (void)hipStreamSynchronize(x.cx->stream); if (x.ev_streamed) (void)hipEventDestroy(x.ev_streamed); x.bs.release(); x.dp.release(); x.ss.release(); }
+        sb.rd.release(); sb.tb.release(); sb.guided.release();
         if (sb.ev_streamed) (void)hipEventDestroy(sb.ev_streamed);
     }
     delete b;
@@ -749,12 +786,38 @@ int gasm_batch_build(gasm_batch* b, int k, uint64_t genome_len_hint) {
     if (!b) { gasm_set_error("batch is null"); return GASM_ERR_INVALID; }
     b->built = false; b->scored = false;
     for (SubBatch& sb : b->sub) {
-        sb.paths_ready = false; sb.ss.valid = false; sb.ss.launched = false;
-        const bool lane = score_lane(b, sb);
-        sb.bs.ev_before_dedup = lane ? sb.ev_scored : nullptr;      // the last step's scoring still searches the directories this build's de-duplication rewrites
-        GCHK(pipeline_build(sb.cx, sb.rd, k, genome_len_hint, sb.bs));
-        if (lane) HIPCHK(hipEventRecord(sb.ev_built, sb.cx->stream));
+        // consecutive steps take the two slots in turn (one-block batches): this build does not wait for the last step's graph
+        // and scoring, it runs beside them.  A change of k rewrites the tile tables both slots read: everything drains first.
+        const int pp = env_int("GASM_PINGPONG", 1);
+        sb.pingpong = b->sub.size() == 1 && pp != 0;
+        if (sb.pingpong && sb.slot[0].cx == nullptr && sb.slot[1].cx == nullptr) {       // (fixed with the first build)
+            sb.pp_mode = pp;
+            sb.n_slots = std::max(2, std::min(4, env_int("GASM_STEP_SLOTS", 3)));
+        }
+        if (sb.pingpong) {
+            if (b->last_k && b->last_k != k) for (StepSlot& x : sb.slot) if (x.cx) HIPCHK(hipStreamSynchronize(x.cx->stream));
+            sb.cur = (sb.cur + 1) % sb.n_slots;
+        }
+        StepSlot& st = sb.S();
+        st.paths_ready = false; st.ss.valid = false; st.ss.launched = false;
+        if (sb.pingpong) {
+            // the streaming kernels of consecutive steps take turns (two of them at once only share the HBM they are both bound by):
+            // this build's partition waits for the other slot's de-duplication, and runs beside that slot's graph and scoring
+            StepSlot& other = sb.slot[(sb.cur + sb.n_slots - 1) % sb.n_slots];
+            const bool chain = sb.pp_mode != 2 && env_flag("GASM_PINGPONG_CHAIN", false);
+            st.bs.stream_ctx = sb.pp_mode == 2 ? sb.cx : nullptr;
+            if (chain && !st.ev_streamed && hipEventCreateWithFlags(&st.ev_streamed, hipEventDisableTiming) != hipSuccess) st.ev_streamed = nullptr;
+            st.bs.ev_streamed = chain ? st.ev_streamed : nullptr;
+            st.bs.ev_wait = chain ? other.ev_streamed : nullptr;      // (never recorded yet: no wait)
+        }
+        const bool lane = !sb.pingpong && score_lane(b, sb);
+        const bool lane_before = sb.lane_last;      // (the lane switched off between two builds: its last scoring is still waited for)
+        sb.lane_last = lane;
+        st.bs.ev_before_dedup = (lane || lane_before) ? sb.ev_scored : nullptr;      // the last step's scoring still searches the directories this build's de-duplication rewrites
+        GCHK(pipeline_build(st.cx, sb.rd, k, genome_len_hint, st.bs));
+        if (lane) HIPCHK(hipEventRecord(sb.ev_built, st.cx->stream));
     }
+    b->last_k = k;
     b->built = true;
     return GASM_OK;
     API_GUARD_END
@@ -771,22 +834,24 @@ int gasm_batch_score(gasm_batch* b, int kmer, const double* table) {
     }
     for (SubBatch& sb : b->sub) {
         if (new_table || !sb.table_set) {
+            for (StepSlot& x : sb.slot) if (x.cx) HIPCHK(hipStreamSynchronize(x.cx->stream));      // (whatever still scores with the old table)
             GCHK(sb.tb.set_standard(sb.cx, table));
             sb.table_set = true;
         }
         // reads shorter than k (or none): the general scorer, which sizes its tables on the host — after the build's report
-        const bool through_graph = pipeline_score_uses_graph(sb.rd, sb.bs);
+        const bool through_graph = pipeline_score_uses_graph(sb.rd, sb.S().bs);
         if (!through_graph) GCHK(sub_finish(b, sb));
         // through the graph: on the lane, behind the build (its queue, not its completion: stream order does the rest)
-        gasm_ctx* const cx = (through_graph && sb.scx && sb.ev_built && !getenv("GASM_SCORE_VERIFY")) ? sb.scx : sb.cx;
-        if (cx != sb.cx) HIPCHK(hipStreamWaitEvent(cx->stream, sb.ev_built, 0));
+        gasm_ctx* const own = sb.S().cx;
+        gasm_ctx* const cx = (sb.lane_last && through_graph && !getenv("GASM_SCORE_VERIFY")) ? sb.scx : own;
+        if (cx != own) HIPCHK(hipStreamWaitEvent(cx->stream, sb.ev_built, 0));
         else if (sb.scx) HIPCHK(hipStreamSynchronize(sb.scx->stream));
-        if (!sb.paths_ready) {
-            GCHK(pipeline_contig_paths(cx, sb.rd, sb.bs, sb.dp));
-            sb.paths_ready = true;
+        if (!sb.S().paths_ready) {
+            GCHK(pipeline_contig_paths(cx, sb.rd, sb.S().bs, sb.S().dp));
+            sb.S().paths_ready = true;
         }
-        if (!through_graph) pipeline_contig_paths_host(sb.rd, sb.bs, sb.dp);
-        GCHK(pipeline_score_launch(cx, sb.rd, sb.dp, kmer, sb.tb, false, false, sb.ss, &sb.bs));
+        if (!through_graph) pipeline_contig_paths_host(sb.rd, sb.S().bs, sb.S().dp);
+        GCHK(pipeline_score_launch(cx, sb.rd, sb.S().dp, kmer, sb.tb, false, false, sb.S().ss, &sb.S().bs));
         sb.score_cx_last = cx;
         if (sb.ev_scored) HIPCHK(hipEventRecord(sb.ev_scored, cx->stream));
     }
@@ -804,8 +869,8 @@ int gasm_batch_guided(gasm_batch* b) {
     if (b->sub.size() != 1) { gasm_set_error("gasm_batch_guided: batches split into sub-batches are not supported"); return GASM_ERR_STATE; }
     GCHK(batch_finish(b));
     SubBatch& sb = b->sub[0];
-    GCHK(pipeline_score_fetch(sb.score_cx_last ? sb.score_cx_last : sb.cx, sb.ss));
-    return guided_build(sb.cx, sb.rd, sb.bs, sb.dp, sb.ss, sb.tb, b->score_kmer, sb.guided);
+    GCHK(pipeline_score_fetch(sb.score_cx_last ? sb.score_cx_last : sb.S().cx, sb.S().ss));
+    return guided_build(sb.S().cx, sb.rd, sb.S().bs, sb.S().dp, sb.S().ss, sb.tb, b->score_kmer, sb.guided);
     API_GUARD_END
 }
 
@@ -815,7 +880,7 @@ int gasm_batch_fetch_guided(gasm_batch* b, const uint64_t** seg_off, const uint6
     if (!b || !seg_off || !off || !data || !bp_score || !norm_by_len || !kmer_breaks) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (b->sub.size() != 1 || !b->sub[0].guided.valid) { gasm_set_error("fetch before gasm_batch_guided"); return GASM_ERR_STATE; }
     GuidedState& g = b->sub[0].guided;
-    GCHK(guided_fetch_text(b->sub[0].cx, g));
+    GCHK(guided_fetch_text(b->sub[0].S().cx, g));
     *seg_off = g.h_seg_off.data(); *off = g.h_text_off.data(); *data = g.h_text.data();
     *bp_score = g.ss.h_bp.data(); *norm_by_len = g.ss.h_nl.data(); *kmer_breaks = g.ss.h_breaks.data();
     return GASM_OK;
@@ -830,13 +895,13 @@ int gasm_batch_fetch_score_fixed(gasm_batch* b, const int64_t** fx, int* shift) 
     if (b->sub.size() != 1 || !b->scored) { gasm_set_error("gasm_batch_fetch_score_fixed needs a scored, unsplit batch"); return GASM_ERR_STATE; }
     GCHK(batch_finish(b));
     SubBatch& sb = b->sub[0];
-    if (!sb.ss.graph) { gasm_set_error("the batch was not scored through its graph"); return GASM_ERR_STATE; }
-    const u32 P = sb.bs.n_contigs;
+    if (!sb.S().ss.graph) { gasm_set_error("the batch was not scored through its graph"); return GASM_ERR_STATE; }
+    const u32 P = sb.S().bs.n_contigs;
     b->h_fx.resize(P);
-    const size_t fx_off = (sb.ss.stride * 4 + 15) & ~(size_t)15;
+    const size_t fx_off = (sb.S().ss.stride * 4 + 15) & ~(size_t)15;
     HIPCHK(hipSetDevice(sb.cx->device));
-    if (P) HIPCHK(hipMemcpyAsync(b->h_fx.data(), static_cast<const char*>(sb.ss.d_total.p) + fx_off, (size_t)P * 8, hipMemcpyDeviceToHost, sb.cx->stream));
-    HIPCHK(hipStreamSynchronize(sb.cx->stream));
+    if (P) HIPCHK(hipMemcpyAsync(b->h_fx.data(), static_cast<const char*>(sb.S().ss.d_total.p) + fx_off, (size_t)P * 8, hipMemcpyDeviceToHost, sb.S().cx->stream));
+    HIPCHK(hipStreamSynchronize(sb.S().cx->stream));
     *fx = b->h_fx.data();
     *shift = sb.tb.fix_shift;
     return GASM_OK;
@@ -845,7 +910,7 @@ int gasm_batch_fetch_score_fixed(gasm_batch* b, const int64_t** fx, int* shift) 
 
 uint64_t gasm_batch_total_kmers(const gasm_batch* b) {
     u64 n = 0;
-    if (b) for (const SubBatch& sb : b->sub) n += sb.bs.n_kmers;
+    if (b) for (const SubBatch& sb : b->sub) n += sb.S().bs.n_kmers;
     return n;
 }
 uint64_t gasm_batch_total_reads(const gasm_batch* b) { return b ? b->n_reads : 0; }
@@ -855,10 +920,10 @@ int gasm_batch_fetch_distinct(gasm_batch* b, const uint64_t** seg_off, const uin
     if (!b || !seg_off || !keys || !mult || !words) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
     GCHK(batch_finish(b));
-    for (SubBatch& sb : b->sub) GCHK(pipeline_fetch_distinct(sb.cx, sb.rd, sb.bs));
-    *words = b->sub[0].bs.words;
+    for (SubBatch& sb : b->sub) GCHK(pipeline_fetch_distinct(sb.S().cx, sb.rd, sb.S().bs));
+    *words = b->sub[0].S().bs.words;
     if (b->sub.size() == 1) {
-        BuildState& bs = b->sub[0].bs;
+        BuildState& bs = b->sub[0].S().bs;
         *seg_off = bs.h_seg_doff.data(); *keys = bs.h_dk_key.data(); *mult = bs.h_dk_cnt.data();
         return GASM_OK;
     }
@@ -866,10 +931,10 @@ int gasm_batch_fetch_distinct(gasm_batch* b, const uint64_t** seg_off, const uin
     b->h_dk_key.clear(); b->h_dk_cnt.clear();
     u64 base = 0;
     for (SubBatch& sb : b->sub) {
-        for (u32 s = sb.seg0; s <= sb.seg1; ++s) b->h_seg_doff[s] = base + sb.bs.h_seg_doff[s - sb.seg0];
-        base += sb.bs.d_total;
-        b->h_dk_key.insert(b->h_dk_key.end(), sb.bs.h_dk_key.begin(), sb.bs.h_dk_key.end());
-        b->h_dk_cnt.insert(b->h_dk_cnt.end(), sb.bs.h_dk_cnt.begin(), sb.bs.h_dk_cnt.end());
+        for (u32 s = sb.seg0; s <= sb.seg1; ++s) b->h_seg_doff[s] = base + sb.S().bs.h_seg_doff[s - sb.seg0];
+        base += sb.S().bs.d_total;
+        b->h_dk_key.insert(b->h_dk_key.end(), sb.S().bs.h_dk_key.begin(), sb.S().bs.h_dk_key.end());
+        b->h_dk_cnt.insert(b->h_dk_cnt.end(), sb.S().bs.h_dk_cnt.begin(), sb.S().bs.h_dk_cnt.end());
     }
     *seg_off = b->h_seg_doff.data(); *keys = b->h_dk_key.data(); *mult = b->h_dk_cnt.data();
     return GASM_OK;
@@ -881,17 +946,17 @@ int gasm_batch_fetch_graph(gasm_batch* b, const uint8_t** edge_flags, const uint
     if (!b || !edge_flags || !edge_next) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
     GCHK(batch_finish(b));
-    for (SubBatch& sb : b->sub) GCHK(pipeline_fetch_graph(sb.cx, sb.rd, sb.bs));
+    for (SubBatch& sb : b->sub) GCHK(pipeline_fetch_graph(sb.S().cx, sb.rd, sb.S().bs));
     if (b->sub.size() == 1) {
-        *edge_flags = b->sub[0].bs.h_eflag.data(); *edge_next = b->sub[0].bs.h_nxt.data();
+        *edge_flags = b->sub[0].S().bs.h_eflag.data(); *edge_next = b->sub[0].S().bs.h_nxt.data();
         return GASM_OK;
     }
     b->h_eflag.clear(); b->h_nxt.clear();
     u32 base = 0;
     for (SubBatch& sb : b->sub) {
-        b->h_eflag.insert(b->h_eflag.end(), sb.bs.h_eflag.begin(), sb.bs.h_eflag.end());
-        for (u32 v : sb.bs.h_nxt) b->h_nxt.push_back(v == 0xFFFFFFFFu ? v : v + base);
-        base += sb.bs.d_total;
+        b->h_eflag.insert(b->h_eflag.end(), sb.S().bs.h_eflag.begin(), sb.S().bs.h_eflag.end());
+        for (u32 v : sb.S().bs.h_nxt) b->h_nxt.push_back(v == 0xFFFFFFFFu ? v : v + base);
+        base += sb.S().bs.d_total;
     }
     *edge_flags = b->h_eflag.data(); *edge_next = b->h_nxt.data();
     return GASM_OK;
@@ -903,9 +968,9 @@ int gasm_batch_fetch_contigs(gasm_batch* b, const uint64_t** seg_contig_off, con
     if (!b || !seg_contig_off || !off || !data) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     if (!b->built) { gasm_set_error("fetch before build"); return GASM_ERR_STATE; }
     GCHK(batch_finish(b));
-    for (SubBatch& sb : b->sub) GCHK(pipeline_fetch_contigs(sb.cx, sb.rd, sb.bs));
+    for (SubBatch& sb : b->sub) GCHK(pipeline_fetch_contigs(sb.S().cx, sb.rd, sb.S().bs));
     if (b->sub.size() == 1) {
-        BuildState& bs = b->sub[0].bs;
+        BuildState& bs = b->sub[0].S().bs;
         *seg_contig_off = bs.h_seg_coff.data(); *off = bs.h_c_off.data(); *data = bs.h_contigs.data();
         return GASM_OK;
     }
@@ -913,11 +978,11 @@ int gasm_batch_fetch_contigs(gasm_batch* b, const uint64_t** seg_contig_off, con
     b->h_c_off.clear(); b->h_contigs.clear();
     u64 cbase = 0, bbase = 0;
     for (SubBatch& sb : b->sub) {
-        for (u32 s = sb.seg0; s <= sb.seg1; ++s) b->h_seg_coff[s] = cbase + sb.bs.h_seg_coff[s - sb.seg0];
-        for (u32 c = 0; c < sb.bs.n_contigs; ++c) b->h_c_off.push_back(bbase + sb.bs.h_c_off[c]);
-        cbase += sb.bs.n_contigs;
-        bbase += sb.bs.contig_bases;
-        b->h_contigs.insert(b->h_contigs.end(), sb.bs.h_contigs.begin(), sb.bs.h_contigs.end());
+        for (u32 s = sb.seg0; s <= sb.seg1; ++s) b->h_seg_coff[s] = cbase + sb.S().bs.h_seg_coff[s - sb.seg0];
+        for (u32 c = 0; c < sb.S().bs.n_contigs; ++c) b->h_c_off.push_back(bbase + sb.S().bs.h_c_off[c]);
+        cbase += sb.S().bs.n_contigs;
+        bbase += sb.S().bs.contig_bases;
+        b->h_contigs.insert(b->h_contigs.end(), sb.S().bs.h_contigs.begin(), sb.S().bs.h_contigs.end());
     }
     b->h_c_off.push_back(bbase);
     *seg_contig_off = b->h_seg_coff.data(); *off = b->h_c_off.data(); *data = b->h_contigs.data();
@@ -930,16 +995,16 @@ int gasm_batch_fetch_scores(gasm_batch* b, const double** bp_score, const double
     API_GUARD_BEGIN
     if (!b || !bp_score || !norm_by_break_freqs || !norm_by_len || !kmer_breaks || !sequence_len) { gasm_set_error("null argument"); return GASM_ERR_INVALID; }
     GCHK(batch_finish(b));
-    for (SubBatch& sb : b->sub) GCHK(pipeline_score_fetch(sb.score_cx_last ? sb.score_cx_last : sb.cx, sb.ss));
+    for (SubBatch& sb : b->sub) GCHK(pipeline_score_fetch(sb.score_cx_last ? sb.score_cx_last : sb.S().cx, sb.S().ss));
     if (b->sub.size() == 1) {
-        ScoreState& ss = b->sub[0].ss;
+        ScoreState& ss = b->sub[0].S().ss;
         *bp_score = ss.h_bp.data(); *norm_by_break_freqs = ss.h_nf.data(); *norm_by_len = ss.h_nl.data();
         *kmer_breaks = ss.h_breaks.data(); *sequence_len = ss.h_len.data();
         return GASM_OK;
     }
     b->h_bp.clear(); b->h_nf.clear(); b->h_nl.clear(); b->h_breaks.clear(); b->h_len.clear();
     for (SubBatch& sb : b->sub) {
-        ScoreState& ss = sb.ss;
+        ScoreState& ss = sb.S().ss;
         b->h_bp.insert(b->h_bp.end(), ss.h_bp.begin(), ss.h_bp.end());
         b->h_nf.insert(b->h_nf.end(), ss.h_nf.begin(), ss.h_nf.end());
         b->h_nl.insert(b->h_nl.end(), ss.h_nl.begin(), ss.h_nl.end());

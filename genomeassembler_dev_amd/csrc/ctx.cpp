@@ -86,11 +86,14 @@ int gasm_ctx::prof_collect() {
     return GASM_OK;
 }
 
-static gasm_ctx* ctx_new(int device, int n_cu) {
+static gasm_ctx* ctx_new(int device, int n_cu, bool high_priority = false) {
     gasm_ctx* c = new gasm_ctx();
     c->device = device;
     c->n_cu = n_cu;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    int lo = 0, hi = 0;                    // (numerically lower = served first)
+    if (high_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;
+    if ((high_priority && hi != lo ? hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi)
+                                   : hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete c;
         gasm_set_error("hipStreamCreate failed");
         return nullptr;
@@ -115,6 +118,24 @@ gasm_ctx* gasm_ctx::lane(size_t i) {
         lanes.push_back(l);
     }
     return lanes[i];
+}
+
+gasm_ctx* gasm_ctx::tail_lane(size_t i) {
+    while (tails.size() <= i) {
+        if (hipSetDevice(device) != hipSuccess) return nullptr;
+        gasm_ctx* l = ctx_new(device, n_cu, true);
+        if (!l) return nullptr;
+        l->prof = prof;
+        l->prof_only = prof_only;
+        tails.push_back(l);
+    }
+    return tails[i];
+}
+
+std::vector<gasm_ctx*> gasm_ctx::all_lanes() const {
+    std::vector<gasm_ctx*> v = lanes;
+    v.insert(v.end(), tails.begin(), tails.end());
+    return v;
 }
 
 extern "C" int gasm_ctx_create(int device, gasm_ctx** out) {
@@ -142,8 +163,9 @@ extern "C" int gasm_ctx_create(int device, gasm_ctx** out) {
 
 extern "C" void gasm_ctx_destroy(gasm_ctx* c) {
     if (!c) return;
-    for (gasm_ctx* l : c->lanes) gasm_ctx_destroy(l);
+    for (gasm_ctx* l : c->all_lanes()) gasm_ctx_destroy(l);
     c->lanes.clear();
+    c->tails.clear();
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
@@ -156,7 +178,7 @@ extern "C" void gasm_ctx_destroy(gasm_ctx* c) {
 extern "C" int gasm_ctx_sync(gasm_ctx* c) {
     if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
     HIPCHK(hipStreamSynchronize(c->stream));
-    for (gasm_ctx* l : c->lanes) HIPCHK(hipStreamSynchronize(l->stream));
+    for (gasm_ctx* l : c->all_lanes()) HIPCHK(hipStreamSynchronize(l->stream));
     return GASM_OK;
 }
 
@@ -166,7 +188,7 @@ extern "C" int gasm_profile_enable(gasm_ctx* c, int on) {
     if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
     if (!on && c->prof) GCHK(c->prof_collect());
     c->prof = on != 0;
-    for (gasm_ctx* l : c->lanes) GCHK(gasm_profile_enable(l, on));
+    for (gasm_ctx* l : c->all_lanes()) GCHK(gasm_profile_enable(l, on));
     return GASM_OK;
 }
 
@@ -182,7 +204,7 @@ extern "C" int gasm_profile_filter(gasm_ctx* c, const char* names) {
             if (*p == 0) break;
         } else cur.push_back(*p);
     }
-    for (gasm_ctx* l : c->lanes) l->prof_only = c->prof_only;
+    for (gasm_ctx* l : c->all_lanes()) l->prof_only = c->prof_only;
     return GASM_OK;
 }
 
@@ -190,7 +212,7 @@ extern "C" int gasm_profile_reset(gasm_ctx* c) {
     if (!c) { gasm_set_error("ctx is null"); return GASM_ERR_INVALID; }
     GCHK(c->prof_collect());
     for (auto& s : c->stages) { s.ms = 0; s.launches = 0; }
-    for (gasm_ctx* l : c->lanes) GCHK(gasm_profile_reset(l));
+    for (gasm_ctx* l : c->all_lanes()) GCHK(gasm_profile_reset(l));
     return GASM_OK;
 }
 
@@ -199,7 +221,7 @@ extern "C" int gasm_profile_read(gasm_ctx* c, int* n, const char* const** names,
     GCHK(c->prof_collect());
     // the lanes' stages are folded into this context's (same kernel names)
     std::vector<ProfStage> all = c->stages;
-    for (gasm_ctx* l : c->lanes) {
+    for (gasm_ctx* l : c->all_lanes()) {
         GCHK(l->prof_collect());
         for (auto& ls : l->stages) {
             bool found = false;

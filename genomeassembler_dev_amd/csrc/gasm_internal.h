@@ -82,6 +82,11 @@ struct gasm_ctx {
     // a gasm_ctx of its own (stream, pinned area, profiler) owned by this one; sync / profile calls on the owner cover them.
     std::vector<gasm_ctx*> lanes;
     gasm_ctx* lane(size_t i);             // created on first use; nullptr on failure
+    // tail lanes: lanes whose stream is served first by the device's dispatcher — the many small kernels behind a build's
+    // streaming pair, while the next build's streaming pair fills the chip from this context's own stream (capi.hip)
+    std::vector<gasm_ctx*> tails;
+    gasm_ctx* tail_lane(size_t i);
+    std::vector<gasm_ctx*> all_lanes() const;
     // small pinned host area for read-backs of counters/flags
     u64* h_pin = nullptr;
     size_t h_pin_words = 0;

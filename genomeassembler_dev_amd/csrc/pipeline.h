@@ -81,6 +81,10 @@ struct BuildState {
     // ---- optional stream choreography of sub-batches (capi.hip): wait for this event before the first kernel, record
     // that one once the streaming kernels (partition + de-duplication) are queued
     hipEvent_t ev_wait = nullptr, ev_streamed = nullptr;
+    // the streaming kernels (partition, de-duplication, gather) on another context's stream (capi.hip: step slots), the
+    // graph on the build's own; ev_slot / ev_dense order the two streams (created on first use, owned by this state)
+    gasm_ctx* stream_ctx = nullptr;
+    hipEvent_t ev_slot = nullptr, ev_dense = nullptr;
     hipEvent_t ev_before_dedup = nullptr;   // waited for between the partition and the de-duplication (the last step's scoring on its lane: capi.hip)
     // ---- report: written by the last kernels of a build into pinned memory, read by pipeline_build_finish
     u32* h_report = nullptr;

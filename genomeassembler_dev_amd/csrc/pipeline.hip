@@ -434,6 +434,8 @@ void BuildState::release() {
         b->release();
     part_valid = false;         // (d_bstart no longer holds the partition's region layout)
     if (h_report) { (void)hipHostFree(h_report); h_report = nullptr; h_report_words = 0; }
+    if (ev_slot) { (void)hipEventDestroy(ev_slot); ev_slot = nullptr; }
+    if (ev_dense) { (void)hipEventDestroy(ev_dense); ev_dense = nullptr; }
 }
 
 void ScoreState::release() {
@@ -852,9 +854,20 @@ int pipeline_build(gasm_ctx* ctx, DevReads& rd, int k, u64 hint, BuildState& bs)
         return GASM_OK;
     }
     distinct_caps(bs, S);
-    if (bs.ev_wait) HIPCHK(hipStreamWaitEvent(ctx->stream, bs.ev_wait, 0));
-    GCHK(launch_distinct(ctx, rd, bs));
-    if (bs.ev_streamed) HIPCHK(hipEventRecord(bs.ev_streamed, ctx->stream));
+    gasm_ctx* const sx = bs.stream_ctx && bs.stream_ctx != ctx ? bs.stream_ctx : ctx;
+    if (sx != ctx) {
+        if (!bs.ev_slot) HIPCHK(hipEventCreateWithFlags(&bs.ev_slot, hipEventDisableTiming));
+        if (!bs.ev_dense) HIPCHK(hipEventCreateWithFlags(&bs.ev_dense, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(bs.ev_slot, ctx->stream));          // whatever this state's last build left queued (graph, scoring, fetches)
+        HIPCHK(hipStreamWaitEvent(sx->stream, bs.ev_slot, 0));
+    }
+    if (bs.ev_wait) HIPCHK(hipStreamWaitEvent(sx->stream, bs.ev_wait, 0));
+    GCHK(launch_distinct(sx, rd, bs));
+    if (bs.ev_streamed) HIPCHK(hipEventRecord(bs.ev_streamed, sx->stream));
+    if (sx != ctx) {
+        HIPCHK(hipEventRecord(bs.ev_dense, sx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, bs.ev_dense, 0));
+    }
     GCHK(launch_graph(ctx, S, bs));
     if (knobs().sync_build) GCHK(pipeline_build_finish(ctx, rd, bs, nullptr));
     return GASM_OK;
