@@ -478,10 +478,11 @@ static int breakscore_impl(gasm_ctx* ctx, DevPaths& dp, const std::function<std:
                 max_bands = std::max<u64>(max_bands, (nq + 4095) / 4096);
                 cells += (double)nq * (double)true_len;
             }
-            // measured: 0.24 us per column and band for a wave alone on its SIMD, 0.58 us with four waves per SIMD
+            // measured (k_levenshtein, round 2): 0.24 us per column and band for a wave alone on its SIMD, 0.58 us with four waves per
+            // SIMD; k_levenshtein2 needs 0.6 of its instructions
             const double per_simd = (double)n_paths / 1024.0;
             const double share = std::max(1.0, 0.6 * std::min(per_simd, 4.0)), rounds = std::max(1.0, per_simd / 4.0);
-            const double gpu_ms = 0.05 + (double)max_bands * (double)(true_len + 63) * 0.00024 * share * rounds;
+            const double gpu_ms = 0.05 + (double)max_bands * (double)(true_len + 63) * 0.00015 * share * rounds;
             const double host_ms = cells / 64.0 * 1.5e-6 / (double)std::max<u64>(1, std::min<u64>(32, n_paths));
             lev_gpu = gpu_ms < host_ms;
         }

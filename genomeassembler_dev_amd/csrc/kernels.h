@@ -177,6 +177,7 @@ template <class K>
 __global__ void k_score_reads_graph(ReadSet rs, GraphView gv, const u64* link, const u32* e_cid, PathSet ps, const long long* dfix,
                                     int kmer, u32 reads_per_wg, u32 chunks, u32 lds_paths, u32* cnt, unsigned long long* sum, int verify, u32* verify_flag);
 __global__ void k_levenshtein(PathSet ps, u32 n_paths, const u64* twords, u32 nt, int infix, u8* carry_ws, u64 carry_stride, int32_t* out);
+__global__ void k_levenshtein2(PathSet ps, u32 n_paths, const u64* twords, u32 nt, int infix, uint4* carry_ws, u64 carry_stride, int32_t* out);
 __global__ void k_score_zero(u32* cnt, unsigned long long* sum, const u32* n_paths_p);
 __global__ void k_score_finish(PathSet ps, const u32* cnt, const unsigned long long* sum, const long long* dfix, const u64* seg_empty,
                                int kmer, double inv_scale, double* bp_score, double* norm_freq, double* norm_len, int32_t* kmer_breaks,

@@ -555,6 +555,172 @@ __global__ void __launch_bounds__(GASM_WG) k_levenshtein(PathSet ps, u32 n_paths
     }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Round 3, second form (k_levenshtein2; GASM_LEV_V=1 keeps the one above): the same systolic band, ~40 instead of ~60
+// instructions per column step —
+//   * the match mask of a step does not wait for the wave shift: lane b's column at step s is s - b, so the lane keeps
+//     its own 64-base window of the target in registers (loaded once per 64 columns) and fetches the mask of that base
+//     from LDS (the lane's four masks, written once per band; layout [base][lane]: conflict-free 64-bit reads) — a
+//     bit-field extract, an address add and a ds_read_b64 where there were two sign extractions and six bit-selects;
+//   * the horizontal delta travels as the producer's own registers: bit 31 of the high words of ph0 and mh0 IS the delta
+//     leaving a full block, so the consumer takes both through an or with a wave-shifted operand and shifts them in with
+//     v_alignbit — no packing, no unpacking (lane 0's input is or-ed in: a register that is zero in every other lane);
+//   * the global distance is read off the LAST column: D[m][n] = n + (vertical +1s) - (vertical -1s), two popcounts per
+//     lane and band — nothing per step (the infix minimum over the columns still follows the last row step by step);
+//   * the deltas leaving the band collect in two shift registers per lane (v_alignbit again); lane 63 stores 16 bytes
+//     per 64 columns and the next band's lane 0 reads them back as bit planes.
+// ----------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 lev2_orn(u32 y, u32 m) {          // m | ~y in one instruction: (y & m) | (~y & -1)
+    u32 r;
+    __asm__("v_bfi_b32 %0, %1, %2, -1" : "=v"(r) : "v"(y), "v"(m));
+    return r;
+}
+
+struct Lev2 {
+    u32 pv_lo, pv_hi, mv_lo, mv_hi;      // vertical deltas of the lane's 64 rows
+    u32 oh_p, oh_n;                      // high words of ph0 / mh0 of the last step: bit 31 = the delta leaving a full block
+    u32 cp, cn;                          // the last 32 deltas that left this lane (+1s, -1s), newest at bit 0
+    // infix, last band: the row of the path's last base (bit tbs of the low or the high word of the lane that holds it)
+    u32 tbs; bool tb_hi; int smask, score, best;
+};
+
+// one column step of a lane.  eq64: the lane's match mask for this column's base; wp / wn: lane 0's incoming delta at
+// bit 31 (zero in the other lanes).  PRED: lanes outside their band keep their state.
+template <bool PRED, bool CARRY, bool FOLLOW>
+__device__ __forceinline__ void lev2_step(Lev2& L, u64 eq64, u32 wp, u32 wn, bool act) {
+    const u32 eq_lo = (u32)eq64, eq_hi = (u32)(eq64 >> 32);
+    const u32 xp = (u32)__builtin_amdgcn_update_dpp(0, (int)L.oh_p, 0x138, 0xf, 0xf, true) | wp;      // wave_shr:1, lane 0 gets 0
+    const u32 xn = (u32)__builtin_amdgcn_update_dpp(0, (int)L.oh_n, 0x138, 0xf, 0xf, true) | wn;
+    const u32 eqn_lo = eq_lo | (xn >> 31);
+    const u32 xv_lo = eq_lo | L.mv_lo, xv_hi = eq_hi | L.mv_hi;
+    const u64 pv = (u64)L.pv_lo | ((u64)L.pv_hi << 32);
+    const u64 sum = ((u64)(eqn_lo & L.pv_lo) | ((u64)(eq_hi & L.pv_hi) << 32)) + pv;
+    const u32 xh_lo = ((u32)sum ^ L.pv_lo) | eqn_lo, xh_hi = ((u32)(sum >> 32) ^ L.pv_hi) | eq_hi;
+    const u32 ph0_lo = lev2_orn(xh_lo | L.pv_lo, L.mv_lo), ph0_hi = lev2_orn(xh_hi | L.pv_hi, L.mv_hi);
+    const u32 mh0_lo = L.pv_lo & xh_lo, mh0_hi = L.pv_hi & xh_hi;
+    const u32 ph_lo = __builtin_amdgcn_alignbit(ph0_lo, xp, 31), ph_hi = __builtin_amdgcn_alignbit(ph0_hi, ph0_lo, 31);
+    const u32 mh_lo = __builtin_amdgcn_alignbit(mh0_lo, xn, 31), mh_hi = __builtin_amdgcn_alignbit(mh0_hi, mh0_lo, 31);
+    const u32 npv_lo = lev2_orn(xv_lo | ph_lo, mh_lo), npv_hi = lev2_orn(xv_hi | ph_hi, mh_hi);
+    const u32 nmv_lo = ph_lo & xv_lo, nmv_hi = ph_hi & xv_hi;
+    if (PRED) {
+        L.pv_lo = act ? npv_lo : L.pv_lo; L.pv_hi = act ? npv_hi : L.pv_hi;
+        L.mv_lo = act ? nmv_lo : L.mv_lo; L.mv_hi = act ? nmv_hi : L.mv_hi;
+    } else {
+        L.pv_lo = npv_lo; L.pv_hi = npv_hi; L.mv_lo = nmv_lo; L.mv_hi = nmv_hi;
+    }
+    L.oh_p = ph0_hi; L.oh_n = mh0_hi;         // (of a lane outside its band: never consumed by a lane inside its own)
+    if (CARRY) { L.cp = __builtin_amdgcn_alignbit(L.cp, ph0_hi, 31); L.cn = __builtin_amdgcn_alignbit(L.cn, mh0_hi, 31); }
+    if (FOLLOW) {
+        const u32 hp = __builtin_amdgcn_ubfe(L.tb_hi ? ph0_hi : ph0_lo, L.tbs, 1), hn = __builtin_amdgcn_ubfe(L.tb_hi ? mh0_hi : mh0_lo, L.tbs, 1);
+        const int d = ((int)hp - (int)hn) & L.smask;
+        L.score += (!PRED || act) ? d : 0;
+        L.best = L.score < L.best ? L.score : L.best;
+    }
+}
+
+template <bool INFIX>
+__device__ __forceinline__ void lev2_path(const PathSet& ps, u32 p, const u64* __restrict__ twords, u32 nt, uint4* __restrict__ carry, u64* __restrict__ lmask,
+                                          int32_t* __restrict__ out) {
+    const u32 ln = threadIdx.x & 63;
+    const u64 pb = ps.p_off[p];
+    const u32 nq = (u32)(ps.p_off[p + 1] - pb);
+    if (nq == 0 || nt == 0) { if (ln == 0) out[p] = 0; return; }     // edlib reports an error, the reference returns 0
+    const u32 nblk = (nq + 63) / 64, nbands = (nblk + 63) / 64;
+    const u32 last_lane = (nblk - 1) & 63, q_last = (nt - 1) >> 6;
+    int vsum = 0;                      // global: vertical deltas of the last column, summed over this lane's blocks
+    Lev2 L;
+    L.score = L.best = (int)nq;        // infix: D[m][0] = m
+    for (u32 band = 0; band < nbands; ++band) {
+        const u32 blk = band * 64 + ln;
+        const bool mine = blk < nblk, last_band = band + 1 == nbands;
+        u64 valid = 0;
+        {
+            u64 H = 0, Lo = 0;
+            if (mine) {
+                const u32 rows = min(64u, nq - blk * 64);
+                u32 h0, l0, h1 = 0, l1 = 0;
+                code_planes32(window32(ps.words, pb + (u64)blk * 64), &h0, &l0);
+                if (rows > 32) code_planes32(window32(ps.words, pb + (u64)blk * 64 + 32), &h1, &l1);
+                H = (u64)h0 | ((u64)h1 << 32);
+                Lo = (u64)l0 | ((u64)l1 << 32);
+                valid = rows == 64 ? ~0ull : ((1ull << rows) - 1);
+            }
+            // (the wave's own 2 KB: a lane reads back only what it wrote itself — no barrier)
+            lmask[0 * 64 + ln] = ~H & ~Lo & valid; lmask[1 * 64 + ln] = ~H & Lo & valid;
+            lmask[2 * 64 + ln] = H & ~Lo & valid;  lmask[3 * 64 + ln] = H & Lo & valid;
+        }
+        L.pv_lo = L.pv_hi = 0xFFFFFFFFu; L.mv_lo = L.mv_hi = 0; L.oh_p = L.oh_n = 0; L.cp = L.cn = 0;
+        const u32 tb = blk + 1 == nblk ? ((nq - 1) & 63) : 63u;
+        L.tbs = tb & 31; L.tb_hi = tb >= 32;
+        L.smask = (INFIX && last_band && ln == last_lane) ? -1 : 0;
+        u32 snap_p = 0, snap_n = 0;
+        // bands with a successor: the columns run until the group of 64 that holds the last one is complete in lane 63
+        const u32 s_end = last_band ? nt + 63 : 64 * q_last + 127;
+        for (u32 s0 = 0; s0 < s_end; s0 += 64) {
+            // lane 0's incoming deltas of columns s0 .. s0 + 63, first column at bit 31 of word 0: +1 everywhere (global) /
+            // nothing (infix) in the first band, else what the band before left
+            u32 wp0 = 0, wp1 = 0, wn0 = 0, wn1 = 0;
+            if (band == 0) { if (!INFIX && ln == 0) wp0 = wp1 = 0xFFFFFFFFu; }
+            else if (ln == 0 && (s0 >> 6) <= q_last) { const uint4 c = carry[s0 >> 6]; wp0 = c.x; wp1 = c.y; wn0 = c.z; wn1 = c.w; }
+            if (s0 >= 64 && s0 + 64 <= nt) {
+                // ---- every lane is inside its band for all 64 columns of this chunk; the lane's columns are s0 - ln .. s0 - ln + 63
+                const u64 W0 = window32(twords, (u64)(s0 - ln)), W1 = window32(twords, (u64)(s0 - ln) + 32);
+                const u32 w[4] = {(u32)(W0 >> 32), (u32)W0, (u32)(W1 >> 32), (u32)W1};
+                if (last_band) {
+                    static_for<64>([&](auto T) {
+                        constexpr u32 t = T;
+                        const u32 base = __builtin_amdgcn_ubfe(w[t >> 4], 30 - 2 * (t & 15), 2);
+                        lev2_step<false, false, INFIX>(L, lmask[base * 64 + ln], (t < 32 ? wp0 : wp1) << (t & 31), (t < 32 ? wn0 : wn1) << (t & 31), true);
+                    });
+                } else {
+                    static_for<64>([&](auto T) {
+                        constexpr u32 t = T;
+                        const u32 base = __builtin_amdgcn_ubfe(w[t >> 4], 30 - 2 * (t & 15), 2);
+                        lev2_step<false, true, false>(L, lmask[base * 64 + ln], (t < 32 ? wp0 : wp1) << (t & 31), (t < 32 ? wn0 : wn1) << (t & 31), true);
+                        if (t == 30) { snap_p = L.cp; snap_n = L.cn; }
+                        if (t == 62 && ln == 63) carry[(s0 >> 6) - 1] = make_uint4(snap_p, L.cp, snap_n, L.cn);      // columns s0 - 64 .. s0 - 1
+                    });
+                }
+            } else {
+                const u32 steps = min(64u, s_end - s0);
+                for (u32 t = 0; t < steps; ++t) {
+                    const u32 j = s0 + t - ln;            // (wraps for s < ln: not active)
+                    const bool act = mine && j < nt;
+                    const u32 base = act ? (u32)(twords[j >> 5] >> (62 - 2 * (j & 31))) & 3u : 0u;
+                    lev2_step<true, true, INFIX>(L, lmask[base * 64 + ln], (t < 32 ? wp0 : wp1) << (t & 31), (t < 32 ? wn0 : wn1) << (t & 31), act);
+                    if (t == 30) { snap_p = L.cp; snap_n = L.cn; }
+                    if (!last_band && t == 62 && s0 >= 64 && ln == 63) carry[(s0 >> 6) - 1] = make_uint4(snap_p, L.cp, snap_n, L.cn);
+                }
+            }
+        }
+        if (mine) vsum += __popcll((((u64)L.pv_hi << 32) | L.pv_lo) & valid) - __popcll((((u64)L.mv_hi << 32) | L.mv_lo) & valid);
+    }
+    int sc;
+    if (INFIX) sc = __shfl(L.best, (int)last_lane, 64);
+    else {
+        // D[m][n] = D[0][n] + the vertical deltas of column n
+        sc = vsum;
+        for (int o = 32; o; o >>= 1) sc += __shfl_xor(sc, o, 64);
+        sc += (int)nt;
+    }
+    if (ln == 0) out[p] = (int32_t)sc;
+}
+
+#ifndef GASM_LEV2_EU
+#define GASM_LEV2_EU 6
+#endif
+__global__ void __launch_bounds__(GASM_WG) __attribute__((amdgpu_waves_per_eu(GASM_LEV2_EU, GASM_LEV2_EU))) k_levenshtein2(PathSet ps, u32 n_paths, const u64* __restrict__ twords, u32 nt, int infix,
+                                                          uint4* __restrict__ carry_ws, u64 carry_stride, int32_t* __restrict__ out) {
+    __shared__ u64 s_mask[GASM_WG / 64][4 * 64];
+    const u32 wave = (blockIdx.x * GASM_WG + threadIdx.x) >> 6, n_waves = gridDim.x * (GASM_WG / 64);
+    uint4* const carry = carry_ws + (u64)wave * carry_stride;         // (nt - 1) / 64 + 1 groups of this wave
+    u64* const lmask = s_mask[threadIdx.x >> 6];
+    for (u32 p = wave; p < n_paths; p += n_waves) {
+        if (infix) lev2_path<true>(ps, p, twords, nt, carry, lmask, out);
+        else lev2_path<false>(ps, p, twords, nt, carry, lmask, out);
+    }
+}
+
 // ================================================================================================================
 // F4 — the R post-processing of score_solutions() (lib/DeNovoAssembler.R:414-445): the two-sample Kolmogorov-Smirnov
 // statistic of a path's path_freq vector against the genome's per-position window probabilities (kmer_from_seq,

@@ -1099,12 +1099,16 @@ int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 ta
     // one wave per path, 32 waves per CU (58 VGPRs: eight per SIMD; 16 -> 32 took 3 % off: the kernel is VALU-bound); every wave parks one byte per target column
     const u32 waves = std::min<u32>(P, (u32)ctx->n_cu * (getenv("GASM_LEV_WAVES") ? (u32)atoi(getenv("GASM_LEV_WAVES")) : 32u));
     const u32 wgs = (waves + GASM_WG / 64 - 1) / (GASM_WG / 64);
-    const u64 stride = (target_len + 64 + 63) & ~(u64)63;
-    st = carry.ensure((size_t)wgs * (GASM_WG / 64) * stride);
+    const bool v2 = env_int("GASM_LEV_V", 2) != 1;
+    // what a band leaves for the next one, per wave: 16 bytes per 64 target columns (v2) / a byte per column
+    const u64 stride = v2 ? ((target_len - 1) / 64 + 2) : ((target_len + 64 + 63) & ~(u64)63);
+    st = carry.ensure((size_t)wgs * (GASM_WG / 64) * stride * (v2 ? 16 : 1));
     if (st == GASM_OK) st = d_out.ensure((size_t)P * 4);
     if (st == GASM_OK) {
-        hipLaunchKernelGGL(k_levenshtein, dim3(wgs), dim3(GASM_WG), 0, ctx->stream, dp.view(), P, twords.as<u64>(), (u32)target_len, infix ? 1 : 0,
-                           carry.as<u8>(), stride, d_out.as<int32_t>());
+        if (v2) hipLaunchKernelGGL(k_levenshtein2, dim3(wgs), dim3(GASM_WG), 0, ctx->stream, dp.view(), P, twords.as<u64>(), (u32)target_len, infix ? 1 : 0,
+                                   carry.as<uint4>(), stride, d_out.as<int32_t>());
+        else hipLaunchKernelGGL(k_levenshtein, dim3(wgs), dim3(GASM_WG), 0, ctx->stream, dp.view(), P, twords.as<u64>(), (u32)target_len, infix ? 1 : 0,
+                                carry.as<u8>(), stride, d_out.as<int32_t>());
         if (hipGetLastError() != hipSuccess) st = GASM_ERR_HIP;
     }
     if (st == GASM_OK && hipMemcpyAsync(lev.data(), d_out.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = GASM_ERR_HIP;

@@ -374,6 +374,29 @@ def test_levenshtein_kernel_against_oracle(qtable):
     assert m["lev_dist_vs_true"].tolist() == [orc.levenshtein(p, t2) for p in paths[2:6]]
 
 
+def test_levenshtein_band_and_group_boundaries(qtable):
+    """k_levenshtein2's seams: paths of 1 .. 3 bands (4096 rows each) against targets whose length sits around the 64-column
+    groups in which a band hands its deltas to the next (1, 63, 64, 65, 127, 128, 129, 191, 4100 columns), both modes;
+    random sequences and mutated copies, so distances are both near the maximum and small."""
+    keys, prob = qtable
+    rng = np.random.default_rng(77)
+    base = _strs(synth.make_segment(909, 9300, planted=False)[None, :])[0]
+    rnd = "".join("ACGT"[i] for i in rng.integers(0, 4, 9000))
+    os.environ["GASM_LEV_GPU"] = "1"
+    try:
+        for nt in (1, 63, 64, 65, 127, 128, 129, 191, 4100):
+            truth = base[37:37 + nt]
+            paths = [base[37:37 + n] for n in (1, 64, 65, 4096, 4097, 8192, 8193, 9000)] + [rnd[:n] for n in (4097, 8200)] + [base[100:100 + 4500][::-1]]
+            reads = [base[:60]]
+            for variant in ("own", "velvet"):
+                m = ga.calc_breakscore(paths, reads, truth, 8, keys, prob, variant=variant, with_lev=True, with_freq=False)
+                ref = [orc.levenshtein(p, truth, infix=(variant == "velvet")) for p in paths]
+                assert m["lev_dist_vs_true"].tolist() == ref, (nt, variant)
+                assert m["lev_device"] == "gpu"
+    finally:
+        del os.environ["GASM_LEV_GPU"]
+
+
 def test_batch_from_fastq_files(tmp_path, qtable):
     """FASTQ in (one file per segment, one of them gzipped FASTA, a read with an N dropped) -> the same contigs and
     scores as the same reads handed over as strings"""
