@@ -189,7 +189,9 @@ __global__ void k_path_freq(PathSet ps, const u32* poscnt, const u32* total, con
                             u32* freq_cnt, u32 n_paths);
 __global__ void k_ks_genome_hist(const u64* gwords, u64 glen, int kmer, const int32_t* drow, u32* hist);
 __global__ void k_path_ks(PathSet ps, const u32* poscnt, const int32_t* drow, int kmer, u32 n_table, const double* pv, const u32* cumy, u32* scratch,
-                          double* out, u32 n_paths);
+                          double* out, u32 n_paths, const u32* list);
+__global__ void k_path_ks2(PathSet ps, const u32* poscnt, const int32_t* drow, int kmer, u32 n_table, const double* pv, const u32* cumy, const u32* run_end,
+                           u32* scratch, double* out, u32* flags, u32 n_paths, u32 bins);
 __global__ void k_cover_mark(const long long* start, const long long* len, u64 n, long long seq_len, int* diff);
 __global__ void k_cover_count(const int* diff, long long seq_len, unsigned long long* covered);
 __global__ void k_prob_dist(PathSet ps, const double* dprob, int kmer, const u64* pd_off, double* out, u32 n_paths);

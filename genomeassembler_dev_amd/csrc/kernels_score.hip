@@ -756,13 +756,14 @@ __device__ __forceinline__ u32 ks_rank_le(const double* __restrict__ pv, u32 n, 
 //   sums in that order);  ny = cumy[n_table - 1]
 __global__ void __launch_bounds__(GASM_WG) k_path_ks(PathSet ps, const u32* __restrict__ poscnt, const int32_t* __restrict__ drow, int kmer,
                                                      u32 n_table, const double* __restrict__ pv, const u32* __restrict__ cumy,
-                                                     u32* __restrict__ scratch, double* __restrict__ out, u32 n_paths) {
+                                                     u32* __restrict__ scratch, double* __restrict__ out, u32 n_paths, const u32* __restrict__ list) {
     __shared__ u32 s_n[2];
     __shared__ double s_best[GASM_WG / 64];
     u32* const cnt = scratch + (u64)blockIdx.x * 2 * n_table;       // per-row counts of the path
     u32* const srt = cnt + n_table;                                  // its non-zero counts, ascending
     const u32 ny = n_table ? cumy[n_table - 1] : 0u;
-    for (u32 p = blockIdx.x; p < n_paths; p += gridDim.x) {
+    for (u32 pi = blockIdx.x; pi < n_paths; pi += gridDim.x) {
+        const u32 p = list ? list[pi] : pi;                          // (list: the paths k_path_ks2 left to this kernel)
         const u64 pb = ps.p_off[p];
         const u32 len = (u32)(ps.p_off[p + 1] - pb);
         for (u32 i = threadIdx.x; i < n_table; i += GASM_WG) cnt[i] = 0;
@@ -834,6 +835,125 @@ __global__ void __launch_bounds__(GASM_WG) k_path_ks(PathSet ps, const u32* __re
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
         if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double b = s_best[0];
+            for (int w = 1; w < GASM_WG / 64; ++w) b = s_best[w] > b ? s_best[w] : b;
+            out[p] = (total && ny && n_table) ? b : __builtin_nan("");      // nothing matched: path_freq is all NaN, R has no x
+        }
+        __syncthreads();
+    }
+}
+
+// #{r : pv[r] < t}
+__device__ __forceinline__ u32 ks_rank_lt(const double* __restrict__ pv, u32 n, double t) {
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 m = (lo + hi) >> 1; if (pv[m] < t) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+// Round 3: the same statistic without a pass over the table per path.  k_path_ks zeroes, compacts and walks all n_table
+// (~70 k) rows for every path and sorts the non-zero counts; here
+//   * the rows a path touches are listed as they are first touched (the atomic add that finds a zero) and reset from
+//     that list, so the per-workgroup counts stay zero between paths;
+//   * the counts are small integers: a histogram over their VALUES (KS_BINS bins in LDS) replaces the sort — its prefix
+//     sums are the ranks, its non-empty bins the distinct sample values (a path with a count >= KS_BINS is left to
+//     k_path_ks: flags[p] = 1);
+//   * of the genome's sample values only those next to a value of the path's sample can attain the supremum: between two
+//     consecutive values of the path's sample Fx is constant and Fy is monotone, so |Fx - Fy| peaks at the first and the
+//     last genome value of the interval (run_end[r]: the last index of the run of equal probabilities that holds r).
+// Same candidates' maximum as k_path_ks, hence the same double.
+#define KS_BINS 1024
+__global__ void __launch_bounds__(GASM_WG) k_path_ks2(PathSet ps, const u32* __restrict__ poscnt, const int32_t* __restrict__ drow, int kmer,
+                                                      u32 n_table, const double* __restrict__ pv, const u32* __restrict__ cumy, const u32* __restrict__ run_end,
+                                                      u32* __restrict__ scratch, double* __restrict__ out, u32* __restrict__ flags, u32 n_paths, u32 bins) {
+    __shared__ u32 s_hist[KS_BINS];          // bin c: rows with count c; then the inclusive prefix (count | non-empty << 20)
+    __shared__ u32 s_dv[KS_BINS + 1], s_dc[KS_BINS + 1];     // the distinct values (counts) ascending and the ranks behind them
+    __shared__ u32 s_n[4];
+    __shared__ u32 s_w[GASM_WG / 64];
+    __shared__ double s_best[GASM_WG / 64];
+    u32* const cnt = scratch + (u64)blockIdx.x * 2 * n_table;       // per-row counts of the path: zero between paths
+    u32* const touched = cnt + n_table;
+    const u32 ny = n_table ? cumy[n_table - 1] : 0u;
+    const u32 ln = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (u32 p = blockIdx.x; p < n_paths; p += gridDim.x) {
+        const u64 pb = ps.p_off[p];
+        const u32 len = (u32)(ps.p_off[p + 1] - pb);
+        for (u32 i = threadIdx.x; i < KS_BINS; i += GASM_WG) s_hist[i] = 0;
+        if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
+        __syncthreads();
+        u32 tot_local = 0;
+        for (u32 j = threadIdx.x; j < len; j += GASM_WG) {
+            const u32 c = poscnt[pb + j];
+            if (!c) continue;
+            tot_local += c;
+            u32 idx;
+            if (break_window(ps.words, pb, len, j, kmer, &idx)) {
+                const int32_t row = drow[idx];
+                if (row >= 0 && atomicAdd(&cnt[row], c) == 0) touched[atomicAdd(&s_n[0], 1u)] = (u32)row;
+            }
+        }
+        atomicAdd(&s_n[1], tot_local);
+        __syncthreads();
+        const u32 nnz = s_n[0], total = s_n[1];
+        for (u32 i = threadIdx.x; i < nnz; i += GASM_WG) {
+            const u32 row = touched[i], c = cnt[row];
+            cnt[row] = 0;
+            if (c < bins) atomicAdd(&s_hist[c], 1u);
+            else s_n[2] = 1;
+        }
+        __syncthreads();
+        if (s_n[2]) {                                  // a count beyond the histogram: the general kernel takes this path
+            if (threadIdx.x == 0) { flags[p] = 1; out[p] = __builtin_nan(""); }
+            __syncthreads();
+            continue;
+        }
+        // ---- inclusive prefix over the bins, four per thread: rows with a count <= c, and how many bins up to c are non-empty
+        {
+            u32 v[KS_BINS / GASM_WG], run = 0;
+#pragma unroll
+            for (u32 q = 0; q < KS_BINS / GASM_WG; ++q) { const u32 h = s_hist[threadIdx.x * (KS_BINS / GASM_WG) + q]; run += h | (h ? 1u << 20 : 0u); v[q] = run; }
+            const u32 inc = wave_incl_scan(run);
+            if (ln == 63) s_w[wv] = inc;
+            __syncthreads();
+            u32 before = inc - run;
+            for (u32 w = 0; w < wv; ++w) before += s_w[w];
+#pragma unroll
+            for (u32 q = 0; q < KS_BINS / GASM_WG; ++q) {
+                const u32 c = threadIdx.x * (KS_BINS / GASM_WG) + q, incl = before + v[q];
+                if (s_hist[c]) { const u32 k = (incl >> 20) - 1; s_dv[k] = c; s_dc[k] = incl & 0xFFFFFu; }
+            }
+            if (threadIdx.x == GASM_WG - 1) s_n[3] = (before + run) >> 20;        // distinct non-zero values
+        }
+        __syncthreads();
+        const u32 nd = s_n[3];
+        double best = 0.0;
+        if (total && ny && n_table) {
+            const double dnx = (double)n_table, dny = (double)ny, dtot = (double)total;
+            const u32 nzero = n_table - nnz;
+            auto fy = [&](u32 r) { return (double)cumy[r] / dny; };
+            auto upd = [&](double d) { best = d > best ? d : best; };
+            // item -1: the sample value 0 (rows the path never touches), item k >= 0: count s_dv[k]
+            for (u32 it = threadIdx.x; it < nd + 1; it += GASM_WG) {
+                const bool zero_item = it == 0;
+                if (zero_item && !nzero) {
+                    // no value 0: the genome's values below the path's smallest value see Fx = 0
+                    const u32 hi = nd ? ks_rank_lt(pv, n_table, (double)s_dv[0] / dtot) : n_table;
+                    if (hi) { upd(fy(run_end[0])); upd(fy(hi - 1)); }
+                    continue;
+                }
+                const double v = zero_item ? 0.0 : (double)s_dv[it - 1] / dtot;
+                const double fx = (double)(nzero + (zero_item ? 0u : s_dc[it - 1])) / dnx;
+                const u32 ry = ks_rank_le(pv, n_table, v);
+                upd(fabs(fx - (ry ? (double)cumy[ry - 1] : 0.0) / dny));                   // at the path's own value
+                const u32 lo = ks_rank_lt(pv, n_table, v), hi = it < nd ? ks_rank_lt(pv, n_table, (double)s_dv[it] / dtot) : n_table;
+                if (lo < hi) { upd(fabs(fx - fy(run_end[lo]))); upd(fabs(fx - fy(hi - 1))); }    // the genome's values in [v, next value)
+                if (zero_item && lo) { upd(fy(run_end[0])); upd(fy(lo - 1)); }                   // (probabilities below 0: Fx = 0 there)
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { const double o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+        if (ln == 0) s_best[wv] = best;
         __syncthreads();
         if (threadIdx.x == 0) {
             double b = s_best[0];

@@ -1096,8 +1096,12 @@ int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 ta
     if (st == GASM_OK && hipMemcpyAsync(&herr, err.p, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
     if (st == GASM_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = GASM_ERR_HIP;
     if (st != GASM_OK || herr) { ascii.release(); err.release(); twords.release(); return st; }   // not ACGT: host routine
-    // one wave per path, 32 waves per CU (58 VGPRs: eight per SIMD; 16 -> 32 took 3 % off: the kernel is VALU-bound); every wave parks one byte per target column
-    const u32 waves = std::min<u32>(P, (u32)ctx->n_cu * (getenv("GASM_LEV_WAVES") ? (u32)atoi(getenv("GASM_LEV_WAVES")) : 32u));
+    // a wave per path, in the order of the paths (scaffolds come longest first): the dispatcher hands the next workgroup to
+    // the CU that has room, which balances better than a fixed share of paths per resident wave (22 053 scaffolds of one
+    // segment: 329 -> 318 ms); what a wave parks for its next band is 16 bytes per 64 target columns, capped at 2 GB in all
+    const u64 per_wave = (((u64)target_len - 1) / 64 + 2) * 16;
+    const u32 cap = (u32)std::max<u64>((u64)ctx->n_cu * 32u, std::min<u64>(1u << 20, (2ull << 30) / per_wave));
+    const u32 waves = std::min<u32>(P, getenv("GASM_LEV_WAVES") ? (u32)ctx->n_cu * (u32)atoi(getenv("GASM_LEV_WAVES")) : cap);
     const u32 wgs = (waves + GASM_WG / 64 - 1) / (GASM_WG / 64);
     const bool v2 = env_int("GASM_LEV_V", 2) != 1;
     // what a band leaves for the next one, per wave: 16 bytes per 64 target columns (v2) / a byte per column
@@ -1155,14 +1159,42 @@ int pipeline_ks(gasm_ctx* ctx, DevPaths& dp, ScoreState& ss, const ScoreTable& t
     for (u32 r = 0; r < NT; ++r) { pv[r] = tb.h_row_prob[order[r]]; run += h_hist[order[r]]; cumy[r] = (u32)run; }
     GCHK(h2d(ctx, d_pv, pv.data(), (size_t)NT * 8));
     GCHK(h2d(ctx, d_cumy, cumy.data(), (size_t)NT * 4));
-    // ---- the paths' side
-    const u32 grid = std::min<u32>(P, (u32)ctx->n_cu * 2u);
+    // ---- the paths' side: k_path_ks2 (histogram over the counts' values); a path with a count beyond its bins goes to k_path_ks
+    const u32 bins = (u32)std::max(2, std::min(1024, env_int("GASM_DBG_KS_BINS", 1024)));
+    const bool v2 = env_int("GASM_KS_V", 2) != 1 && NT > 0;
+    const u32 grid = std::min<u32>(P, (u32)ctx->n_cu * (v2 ? 4u : 2u));
     GCHK(scratch.ensure((size_t)grid * 2 * std::max<u32>(NT, 1) * 4));
     GCHK(d_out.ensure((size_t)P * 8));
-    GLAUNCH(ctx, "k_path_ks", k_path_ks, dim3(grid), dim3(GASM_WG), 0, dp.view(), ss.d_poscnt.as<u32>(), tb.d_row.as<int32_t>(), kmer, NT, d_pv.as<double>(),
-            d_cumy.as<u32>(), scratch.as<u32>(), d_out.as<double>(), P);
-    HIPCHK(hipMemcpyAsync(ks.data(), d_out.p, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<u32> todo;
+    if (v2) {
+        DBuf d_run_end, d_flags;
+        struct Rel2 { std::vector<DBuf*> v; ~Rel2() { for (DBuf* b : v) b->release(); } } rel2{{&d_run_end, &d_flags}};
+        std::vector<u32> run_end(NT);
+        for (u32 r = NT; r-- > 0;) run_end[r] = (r + 1 < NT && pv[r + 1] == pv[r]) ? run_end[r + 1] : r;
+        GCHK(h2d(ctx, d_run_end, run_end.data(), (size_t)NT * 4));
+        GCHK(d_flags.ensure((size_t)P * 4));
+        HIPCHK(hipMemsetAsync(d_flags.p, 0, (size_t)P * 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(scratch.p, 0, (size_t)grid * 2 * NT * 4, ctx->stream));         // (the kernel keeps the counts zero between paths)
+        GLAUNCH(ctx, "k_path_ks2", k_path_ks2, dim3(grid), dim3(GASM_WG), 0, dp.view(), ss.d_poscnt.as<u32>(), tb.d_row.as<int32_t>(), kmer, NT, d_pv.as<double>(),
+                d_cumy.as<u32>(), d_run_end.as<u32>(), scratch.as<u32>(), d_out.as<double>(), d_flags.as<u32>(), P, bins);
+        std::vector<u32> h_flags(P);
+        HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ks.data(), d_out.p, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (u32 p = 0; p < P; ++p) if (h_flags[p]) todo.push_back(p);
+        if (todo.empty()) return GASM_OK;
+    }
+    {
+        DBuf d_list;
+        struct Rel3 { DBuf* b; ~Rel3() { b->release(); } } rel3{&d_list};
+        const u32 n = v2 ? (u32)todo.size() : P;
+        if (v2) GCHK(h2d(ctx, d_list, todo.data(), (size_t)n * 4));
+        const u32 g1 = std::min<u32>(n, (u32)ctx->n_cu * 2u);
+        GLAUNCH(ctx, "k_path_ks", k_path_ks, dim3(g1), dim3(GASM_WG), 0, dp.view(), ss.d_poscnt.as<u32>(), tb.d_row.as<int32_t>(), kmer, NT, d_pv.as<double>(),
+                d_cumy.as<u32>(), scratch.as<u32>(), d_out.as<double>(), n, v2 ? d_list.as<u32>() : (const u32*)nullptr);
+        HIPCHK(hipMemcpyAsync(ks.data(), d_out.p, (size_t)P * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return GASM_OK;
 }
 

@@ -45,6 +45,28 @@ def test_ks_statistic_against_oracle_and_scipy(qtable):
             assert abs(orc.ks_statistic(m["path_freq"][i], y) - ref) < 1e-12
 
 
+def test_ks_kernels_agree_bit_for_bit(qtable):
+    """k_path_ks2 (histogram over the counts' values, genome values next to the path's values only) returns the same double
+    as the general k_path_ks (every table row, sorted counts) — also for the paths it hands back to it (a count beyond its
+    bins: forced here with three bins) and with a table in which many rows share a probability (uniform)."""
+    keys, prob = qtable
+    os = __import__("os")
+    for seed, table in ((43, prob), (44, ga.qtable.uniform())):
+        truth, reads, paths = _case(seed, rows=60)
+        paths = paths + ["ACGTACGTACGTTTTT", truth[:40], truth]
+        got = {}
+        for name, env in (("v2", {}), ("v1", {"GASM_KS_V": "1"}), ("v2_3bins", {"GASM_DBG_KS_BINS": "3"})):
+            os.environ.update(env)
+            try:
+                got[name] = ga.calc_breakscore(paths, reads, truth, 8, keys, table, with_lev=False, with_freq=False, with_ks=True)["stat_test_KS"]
+            finally:
+                for k in env:
+                    del os.environ[k]
+        a, b, c = (np.asarray(got[n], dtype=np.float64).view(np.uint64) for n in ("v2", "v1", "v2_3bins"))
+        assert (a == b).all() and (c == b).all(), seed
+        assert np.isfinite(got["v2"]).sum() >= len(paths) - 2
+
+
 def test_coverage_percent_against_oracle():
     rng = np.random.default_rng(9)
     for L in (1, 37, 1000, 50000):
