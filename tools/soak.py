@@ -58,6 +58,19 @@ while time.time() - t0 < budget:
             assert sc["kmer_breaks"][a:e].tolist() == o["kmer_breaks"].tolist(), (tag, s, "breaks")
             assert np.abs(sc["bp_score"][a:e] - o["bp_score"]).max(initial=0.0) < 1e-9, (tag, s, "score")
         segs += 1
+    # step slots: further steps on the same batch without reading anything in between — another k (everything drains), then
+    # the first k three times in flight; the last step's results are the first step's, bit for bit
+    if rounds % 2 == 0:
+        k2 = int(rng.choice([kk for kk in (3, 9, 21, 31, 33, 51) if kk <= rl and kk != k] or [k]))
+        b.build(k2, genome_len_hint=hint).score(8, prob)
+        rs0 = [x.tobytes().decode() for x in reads[off[0]:off[1]]]
+        assert b.contigs()[0] == orc.get_contigs(orc.kmers_from_reads(rs0, k2), k2, 1, rows=1)["contigs"], (tag, k2, "contigs at the second k")
+        for _ in range(3):
+            b.build(k, genome_len_hint=hint).score(8, prob)
+        sc3 = b.scores()
+        assert b.contigs() == contigs, (tag, "contigs after three more steps")
+        for name in ("kmer_breaks", "bp_score", "sequence_len", "seg_contig_off"):
+            assert np.array_equal(np.asarray(sc3[name]), np.asarray(sc[name])), (tag, name, "after three more steps")
     # pooled virtual ranks = single GPU
     if rounds % 3 == 0:
         world = int(rng.integers(1, 5))
