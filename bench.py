@@ -181,7 +181,17 @@ def main():
         uid = [pooled.Comm.unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
-        comm = pooled.Comm.rccl(ctx, uid[0], rank, world)       # ncclCommInitRank: also at N = 1, so the one-GPU box runs the RCCL path
+        # ncclCommInitRank: also at N = 1, so the one-GPU box runs the RCCL path.  This RCCL prints its version banner on
+        # stdout when a communicator comes up; stdout is the one JSON line's, so the banner goes to stderr.
+        sys.stdout.flush()
+        keep_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            comm = pooled.Comm.rccl(ctx, uid[0], rank, world)
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep_fd, 1)
+            os.close(keep_fd)
         state = {}
         n_km = int(off[-1]) * (rl - k + 1)
 
@@ -295,13 +305,14 @@ def main():
 
     if roofline and args.mode == "segments":
         roofline["steps_in_flight"] = "consecutive steps of a one-block batch overlap (step slots): durations above are residence times on a shared chip"
-        if prof_alone and prof_alone.get(dom, (0.0, 0))[1]:
+        if prof_alone and any(prof_alone.get(n, (0.0, 0))[1] for n in dominant):
             a_ms = {n: prof_alone[n][0] / prof_alone[n][1] for n in dominant if n in prof_alone and prof_alone[n][1]}
+            adom = max(a_ms, key=a_ms.get)         # (the dominant kernel of THIS pass: its own duration, not its residence time)
             roofline["one_step_in_flight"] = {
-                "steps": args.alone_steps, "ms_per_step": round(dt_alone / args.alone_steps * 1e3, 4), "kernel": dom,
-                "avg_launch_ms": round(a_ms[dom], 4), "achieved": round(alg_bytes[dom] / (a_ms[dom] / 1e3) / 1e9, 1),
-                "frac": round(alg_bytes[dom] / (a_ms[dom] / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
-                "other": {n: {"avg_launch_ms": round(v, 4), "achieved_GBs": round(alg_bytes[n] / (v / 1e3) / 1e9, 1)} for n, v in a_ms.items() if n != dom}}
+                "steps": args.alone_steps, "ms_per_step": round(dt_alone / args.alone_steps * 1e3, 4), "kernel": adom,
+                "avg_launch_ms": round(a_ms[adom], 4), "achieved": round(alg_bytes[adom] / (a_ms[adom] / 1e3) / 1e9, 1),
+                "frac": round(alg_bytes[adom] / (a_ms[adom] / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                "other": {n: {"avg_launch_ms": round(v, 4), "achieved_GBs": round(alg_bytes[n] / (v / 1e3) / 1e9, 1)} for n, v in a_ms.items() if n != adom}}
     if roofline and score_bytes and prof.get("k_score_reads_graph", (0.0, 0))[1]:
         # (low by construction: the scorer's work is index look-ups and compares, not bytes)
         sms = prof["k_score_reads_graph"][0] / prof["k_score_reads_graph"][1]

@@ -18,14 +18,18 @@ stats() {  # name, bench args...
   f=$(find $out/stats_$name -name "*kernel_stats.csv" | head -1)
   cp "$f" $out/${name}_kernel_stats.csv && rm -rf $out/stats_$name
 }
-stats cfg2 || exit 2      # (the default flags: the same command as the bench line)
+stats cfg2 || exit 2      # (the default flags: the same command as the bench line — durations are residence times: steps overlap)
+# one step in flight and every kernel alone on the chip: the kernels' own durations (the bench line's roofline.one_step_in_flight)
+export GASM_PINGPONG=0 GASM_SCORE_LANE=0
+stats cfg2_one_step_in_flight --alone-steps 0 || exit 2
 stats cfg4 --workload cfg4 --steps 5 --warmup 1 || exit 2
 stats pooled_n1 --mode pooled --steps 3 --warmup 1 || exit 2
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_fetch.log 2>&1 || exit 3
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_write.log 2>&1 || exit 4
-python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $out "$head" > $out/pmc_traffic.json
+python3 $GRAFT_REPO_ROOT/tools/pmc_traffic.py $out "$head" > $out/pmc_traffic.json   # (counter passes: one step in flight, see the export above)
 rm -rf $out/pmc_fetch $out/pmc_write
 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVES --kernel-trace --output-format csv -d $out/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_sq.log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $out/pmc_sq k_bucket k_tile k_rank k_score > $out/pmc_sq_summary.txt 2>&1
 rm -rf $out/pmc_sq
+unset GASM_PINGPONG GASM_SCORE_LANE
 echo "profile $tag done"
