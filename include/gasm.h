@@ -226,7 +226,13 @@ const uint64_t* gasm_packed_seg_read_off(const gasm_packed* g);    /* n_segments
 uint64_t gasm_packed_dropped(const gasm_packed* g);
 void gasm_packed_free(gasm_packed* g);
 void gasm_batch_free(gasm_batch* b);
-/* genome_len_hint: expected distinct k-mers per segment (0 = derive from the k-mer count); only sizes buckets */
+/* genome_len_hint: expected distinct k-mers per segment (0 = derive from the k-mer count); only sizes buckets.
+ * build and score only QUEUE their work (no host wait); the fetches below wait for it.  A batch that runs as one block
+ * keeps up to four "step slots" — everything a step writes, on a stream of its own — and consecutive builds take them in
+ * turn, so `build; score; build; score; ...` without a fetch in between runs step n + 1's streaming kernels beside step n's
+ * graph and scoring kernels.  Every step still does all of its work, and every fetch returns the results of the LAST build
+ * and score, bit for bit what one step at a time gives (GASM_PINGPONG=0 in the environment: exactly that; GASM_STEP_SLOTS:
+ * 2..4 slots, default 3). */
 int gasm_batch_build(gasm_batch* b, int k, uint64_t genome_len_hint);
 int gasm_batch_score(gasm_batch* b, int kmer, const double* table);
 uint64_t gasm_batch_total_kmers(const gasm_batch* b);   /* k-mers extracted by the last build */

@@ -202,6 +202,46 @@ def test_overflow_retry_and_skewed_bins():
             b.close()
 
 
+def test_step_slots_reproduce_one_step_in_flight(qtable):
+    """Consecutive steps of a one-block batch take step slots in turn (capi.hip): whatever the number of slots and the way they
+    overlap (GASM_PINGPONG 0 / 1 / 2, GASM_STEP_SLOTS 2..4), every step's results are those of a batch that runs one step
+    at a time — with steps queued without a fetch in between, a change of k (all slots drain), a change of the score
+    table between steps, a step that needs the retry ladder (far too small hint) in the middle, and fetches that must
+    come from the slot of the LAST build."""
+    keys, prob = qtable
+    uni = ga.qtable.uniform()
+    reads, seg_off, _g = synth.make_batch(7, 5000, 90, 18, seed0=4242, planted=True)
+
+    def run(env):
+        os.environ.update(env)
+        try:
+            b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=90)
+            out = []
+            for k, hint, table, fetch in ((21, 5000, prob, False), (21, 5000, prob, False), (21, 5000, prob, True), (31, 5000, prob, True),
+                                          (21, 5000, uni, False), (21, 40, prob, False), (21, 5000, prob, True), (33, 0, uni, True),
+                                          (21, 5000, prob, False), (21, 5000, prob, False), (21, 5000, prob, False), (21, 5000, prob, True)):
+                b.build(k, genome_len_hint=hint).score(8, table)
+                if fetch:
+                    sc = b.scores()
+                    seg, kk, mm, _w = b.distinct()
+                    out.append((b.contigs(), sc["kmer_breaks"].tolist(), sc["bp_score"].tobytes(), np.asarray(seg).tolist(),
+                                np.asarray(kk).tobytes(), np.asarray(mm).tobytes()))
+            b.close()
+            return out
+        finally:
+            for name in env:
+                del os.environ[name]
+
+    ref = run({"GASM_PINGPONG": "0", "GASM_SCORE_LANE": "0"})
+    assert ref[0] == ref[2] == ref[4] and ref[0] != ref[1]          # same k and table again: the same bits; another k: not
+    for env in ({"GASM_PINGPONG": "0"}, {"GASM_PINGPONG": "1", "GASM_STEP_SLOTS": "2"}, {}, {"GASM_PINGPONG": "1", "GASM_STEP_SLOTS": "4"},
+                {"GASM_PINGPONG": "2", "GASM_STEP_SLOTS": "2"}, {"GASM_PINGPONG": "2", "GASM_STEP_SLOTS": "3"}):
+        assert run(env) == ref, env
+    # and against the oracle once (segment 3 at k = 21)
+    rs = _strs(reads[int(seg_off[3]):int(seg_off[4])])
+    assert ref[0][0][3] == orc.get_contigs(orc.kmers_from_reads(rs, 21), 21, 1, rows=1)["contigs"]
+
+
 def test_buckets_no_table_can_hold():
     """Skewed base composition (3 C : 1 A): with all ten bucket bits used, the bucket of the prefix CCCCC still holds more
     distinct k-mers than a table takes (1408 of 128-bit keys, 2816 of 64-bit keys) -> the last rung of the retry ladder,
