@@ -32,6 +32,7 @@ SYMBOLS = {
     "gasm_ctx_sync": (_int, [_vp]),
     "gasm_ctx_stream": (_vp, [_vp]),
     "gasm_get_contigs": (_int, [_vp, _vp, _u64, _int, _int, _int, _PP]),
+    "gasm_get_contigs_from_reads": (_int, [_vp, _vp, _vp, _u64, _int, _int, _int, _PP]),
     "gasm_contigs_count": (_u64, [_vp]),
     "gasm_contigs_data": (_vp, [_vp]),
     "gasm_contigs_offsets": (_vp, [_vp]),

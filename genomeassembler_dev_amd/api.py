@@ -103,6 +103,21 @@ def get_contigs(read_kmers, dbg_kmer, seed, matrix_rows=10000, ctx=None, as_list
         p = C.cast(C.c_char_p(buf), C.c_void_p)
     h = C.c_void_p()
     check(lib().gasm_get_contigs(ctx.h, p, n, int(dbg_kmer), int(seed), int(matrix_rows), C.byref(h)))
+    return _contig_matrix(h, dbg_kmer, as_lists)
+
+
+def get_contigs_from_reads(reads, dbg_kmer, seed, matrix_rows=10000, ctx=None, as_lists=False):
+    """get_kmers_from_reads + get_contigs in one call (gasm_get_contigs_from_reads): the k-mers are taken on the GPU from the
+    packed reads instead of being exploded into len(reads) * (read_len - k + 1) strings first (lib/DeNovoAssembler.R:109-130).
+    reads: list of str / bytes.  Same ContigMatrix as get_contigs(get_kmers_from_reads(reads, k), k, seed)."""
+    ctx = ctx or default_context()
+    buf, off = _pack(reads)
+    h = C.c_void_p()
+    check(lib().gasm_get_contigs_from_reads(ctx.h, buf, _ptr(off), len(reads), int(dbg_kmer), int(seed), int(matrix_rows), C.byref(h)))
+    return _contig_matrix(h, dbg_kmer, as_lists)
+
+
+def _contig_matrix(h, dbg_kmer, as_lists):
     try:
         L = lib()
         nc = L.gasm_contigs_count(h)

@@ -196,17 +196,13 @@ static int breakscore_impl(gasm_ctx* ctx, DevPaths& dp, const std::function<std:
                            int flags, gasm_scores** out);
 
 // ------------------------------------------------------------------------------------------------- get_contigs
-int gasm_get_contigs(gasm_ctx* ctx, const char* kmers, uint64_t n_kmers, int dbg_kmer, int seed, int matrix_rows,
-                     gasm_contigs** out) {
-    API_GUARD_BEGIN
-    if (!ctx || !out || (n_kmers && !kmers)) { gasm_set_error("gasm_get_contigs: null argument"); return GASM_ERR_INVALID; }
-    if (matrix_rows < 0) { gasm_set_error("matrix_rows must be >= 0"); return GASM_ERR_INVALID; }
-    *out = nullptr;
-    // the exploded k-mers are reads of length k with one k-mer each
+// reads (ragged when read_off != nullptr, else n_reads reads of fixed_len) of ONE segment -> contigs + shuffle matrix
+static int contigs_of_reads(gasm_ctx* ctx, const char* bases, const u64* read_off, u64 n_reads, u32 fixed_len, int dbg_kmer, int seed, int matrix_rows,
+                            gasm_contigs** out) {
     DevReads rd;
     BuildState bs;
-    const u64 seg_off[2] = {0, n_kmers};
-    int st = rd.upload(ctx, kmers, nullptr, n_kmers, (u32)dbg_kmer, seg_off, 1);
+    const u64 seg_off[2] = {0, n_reads};
+    int st = rd.upload(ctx, bases, read_off, n_reads, fixed_len, seg_off, 1);
     if (st == GASM_OK) st = pipeline_build(ctx, rd, dbg_kmer, 0, bs);
     if (st == GASM_OK) st = pipeline_fetch_distinct(ctx, rd, bs);
     if (st == GASM_OK) st = pipeline_fetch_contigs(ctx, rd, bs);
@@ -227,6 +223,26 @@ int gasm_get_contigs(gasm_ctx* ctx, const char* kmers, uint64_t n_kmers, int dbg
     if (st != GASM_OK) return st;
     *out = c;
     return GASM_OK;
+}
+
+int gasm_get_contigs(gasm_ctx* ctx, const char* kmers, uint64_t n_kmers, int dbg_kmer, int seed, int matrix_rows,
+                     gasm_contigs** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || (n_kmers && !kmers)) { gasm_set_error("gasm_get_contigs: null argument"); return GASM_ERR_INVALID; }
+    if (matrix_rows < 0) { gasm_set_error("matrix_rows must be >= 0"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    // the exploded k-mers are reads of length k with one k-mer each
+    return contigs_of_reads(ctx, kmers, nullptr, n_kmers, (u32)dbg_kmer, dbg_kmer, seed, matrix_rows, out);
+    API_GUARD_END
+}
+
+int gasm_get_contigs_from_reads(gasm_ctx* ctx, const char* reads, const uint64_t* read_off, uint64_t n_reads, int dbg_kmer, int seed,
+                                int matrix_rows, gasm_contigs** out) {
+    API_GUARD_BEGIN
+    if (!ctx || !out || (n_reads && (!reads || !read_off))) { gasm_set_error("gasm_get_contigs_from_reads: null argument"); return GASM_ERR_INVALID; }
+    if (matrix_rows < 0) { gasm_set_error("matrix_rows must be >= 0"); return GASM_ERR_INVALID; }
+    *out = nullptr;
+    return contigs_of_reads(ctx, reads, read_off, n_reads, 0, dbg_kmer, seed, matrix_rows, out);
     API_GUARD_END
 }
 

@@ -72,6 +72,13 @@ void* gasm_ctx_stream(gasm_ctx* ctx);
  * ---------------------------------------------------------------------------------------------------------------- */
 int gasm_get_contigs(gasm_ctx* ctx, const char* kmers, uint64_t n_kmers, int dbg_kmer, int seed, int matrix_rows,
                      gasm_contigs** out);
+/* The same from the reads themselves — get_kmers_from_reads (lib/DeNovoAssembler.R:109-130: substring() of every read at every
+ * offset, 31 characters per k-mer handed across the R / C++ boundary) and get_contigs in one call: the k-mers are taken on the
+ * GPU from the 2-bit packed reads.  reads: the reads' characters back to back, read_off[n_reads + 1] their offsets; a read
+ * shorter than dbg_kmer has no k-mers.  Same result as gasm_get_contigs on the exploded k-mers (the k-mers' order never
+ * mattered: lib/DeNovoAssembler.cpp:91-122 counts them). */
+int gasm_get_contigs_from_reads(gasm_ctx* ctx, const char* reads, const uint64_t* read_off, uint64_t n_reads, int dbg_kmer, int seed,
+                                int matrix_rows, gasm_contigs** out);
 uint64_t gasm_contigs_count(const gasm_contigs* c);
 const char* gasm_contigs_data(const gasm_contigs* c);
 const uint64_t* gasm_contigs_offsets(const gasm_contigs* c);       /* count+1 */

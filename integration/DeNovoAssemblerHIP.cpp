@@ -64,6 +64,24 @@ std::vector<std::vector<std::string>> get_contigs(const std::vector<std::string>
     return m;
 }
 
+// get_kmers_from_reads (lib/DeNovoAssembler.R:109-130) + get_contigs in one call: the reads go down as they are and the
+// k-mers are taken on the GPU (self$read_kmers need not exist; in DeNovoAssembler.R: get_contigs_from_reads(
+// self$sequencing_reads$read_one, self$dbg_kmer, self$seed) in place of the two steps)
+// [[Rcpp::export]]
+std::vector<std::vector<std::string>> get_contigs_from_reads(const std::vector<std::string>& reads, const int& dbg_kmer, const int& seed) {
+    Flat f(reads);
+    gasm_contigs* c = nullptr;
+    check(gasm_get_contigs_from_reads(the_ctx(), f.data.data(), f.off.data(), reads.size(), dbg_kmer, seed, 10000, &c));
+    const uint64_t n = gasm_contigs_count(c), rows = gasm_contigs_rows(c);
+    std::vector<std::string> contigs = unflat(gasm_contigs_data(c), gasm_contigs_offsets(c), n);
+    const uint32_t* perm = gasm_contigs_perm(c);
+    std::vector<std::vector<std::string>> m(rows, std::vector<std::string>(n));
+    for (uint64_t r = 0; r < rows; ++r)
+        for (uint64_t j = 0; j < n; ++j) m[r][j] = contigs[perm[r * n + j]];
+    gasm_contigs_free(c);
+    return m;
+}
+
 // replaces lib/DeNovoAssembler.cpp:215-305
 // [[Rcpp::export]]
 std::vector<std::string> assemble_contigs(const std::vector<std::vector<std::string>>& contig_matrix, const int& dbg_kmer) {

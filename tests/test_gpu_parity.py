@@ -69,6 +69,10 @@ def test_get_contigs_reference_operating_points(read_len, k):
     # distinct k-mers are the distinct edges: (prefix, suffix) lists must agree too
     assert [d[:-1] for d in m.distinct_kmers()] == ref["edge_prefix"]
     assert [d[1:] for d in m.distinct_kmers()] == ref["edge_suffix"]
+    # the same from the reads themselves (gasm_get_contigs_from_reads: get_kmers_from_reads + get_contigs in one call)
+    m2 = ga.get_contigs_from_reads(reads, k, 1234)
+    assert m2.contigs == m.contigs and np.array_equal(m2.perm, m.perm)
+    assert np.array_equal(m2.distinct_keys, m.distinct_keys) and np.array_equal(m2.distinct_mult, m.distinct_mult)
     assert ga.assemble_contigs(m, k, ctx=ga.default_context()) == orc.assemble_contigs(ref["contigs"], ref["perm"], k)     # merge on the GPU
     assert ga.assemble_contigs(m, k) == orc.assemble_contigs(ref["contigs"], ref["perm"], k)                                 # host merge (no context)
 
@@ -83,6 +87,11 @@ def test_get_contigs_k_range_with_repeats(k):
     assert m.contigs == ref["contigs"]
     assert np.array_equal(m.perm, ref["perm"])
     assert m.distinct_kmers() == ref["distinct"] and m.distinct_mult.tolist() == ref["counts"].tolist()
+    # ragged reads, some shorter than k (no k-mers), through the reads entry
+    rr = [r[:len(r) - (i % 7)] for i, r in enumerate(reads)] + ["ACG"[:min(3, k - 1)], ""]
+    kr = ga.get_kmers_from_reads(rr, k)
+    a, b = ga.get_contigs_from_reads(rr, k, 7, matrix_rows=20), ga.get_contigs(kr, k, 7, matrix_rows=20)
+    assert a.contigs == b.contigs and np.array_equal(a.perm, b.perm) and np.array_equal(a.distinct_mult, b.distinct_mult)
 
 
 def test_get_contigs_edge_cases():
@@ -102,6 +111,12 @@ def test_get_contigs_edge_cases():
     # nothing
     m = ga.get_contigs([], 5, 1, matrix_rows=4)
     assert m.contigs == [] and m.perm.shape == (4, 0)
+    m = ga.get_contigs_from_reads([], 5, 1, matrix_rows=4)
+    assert m.contigs == [] and m.perm.shape == (4, 0)
+    assert ga.get_contigs_from_reads(["ACG", "AC"], 5, 1, matrix_rows=2).contigs == []          # only reads shorter than k
+    assert ga.get_contigs_from_reads([lin, lin[3:11]], 5, 1, matrix_rows=3).contigs == [lin]
+    with pytest.raises(ga.GasmError):
+        ga.get_contigs_from_reads(["ACGTNACGT"], 5, 1)
 
 
 @pytest.mark.parametrize("k,rl", [(15, 50), (41, 90)])

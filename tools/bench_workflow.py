@@ -30,6 +30,8 @@ def timed(name, f):
 
 km = timed("get_kmers_from_reads (host)", lambda: ga.get_kmers_from_reads(reads, k))
 m = timed(f"get_contigs ({rows} shuffles)", lambda: ga.get_contigs(km, k, 1234, matrix_rows=rows))
+m2 = timed("get_contigs_from_reads (one call)", lambda: ga.get_contigs_from_reads(reads, k, 1234, matrix_rows=rows))
+assert m2.contigs == m.contigs and (m2.perm == m.perm).all()
 sc = timed("assemble_contigs (strings back)", lambda: ga.assemble_contigs(m, k, ctx=ga.default_context()))
 print(f"  contigs {len(m.contigs)}, scaffolds {len(sc)}, scaffold bases {sum(map(len, sc))}")
 a = timed("calc_breakscore(strings), no lev", lambda: ga.calc_breakscore(sc, reads, truth, 8, keys, prob, with_lev=False, with_freq=False))
