@@ -619,12 +619,11 @@ __device__ __forceinline__ void lev2_step(Lev2& L, u64 eq64, u32 wp, u32 wn, boo
 }
 
 template <bool INFIX>
-__device__ __forceinline__ void lev2_path(const PathSet& ps, u32 p, const u64* __restrict__ twords, u32 nt, uint4* __restrict__ carry, u64* __restrict__ lmask,
-                                          int32_t* __restrict__ out) {
+// rows: nq bases from base qb of qwords (a lane owns 64 of them), columns: nt bases from base tb0 of twords
+__device__ __forceinline__ void lev2_path(const u64* __restrict__ qwords, u64 qb, u32 nq, const u64* __restrict__ twords, u64 tb0, u32 nt,
+                                          uint4* __restrict__ carry, u64* __restrict__ lmask, int32_t* __restrict__ out_p) {
     const u32 ln = threadIdx.x & 63;
-    const u64 pb = ps.p_off[p];
-    const u32 nq = (u32)(ps.p_off[p + 1] - pb);
-    if (nq == 0 || nt == 0) { if (ln == 0) out[p] = 0; return; }     // edlib reports an error, the reference returns 0
+    const u64 pb = qb;
     const u32 nblk = (nq + 63) / 64, nbands = (nblk + 63) / 64;
     const u32 last_lane = (nblk - 1) & 63, q_last = (nt - 1) >> 6;
     int vsum = 0;                      // global: vertical deltas of the last column, summed over this lane's blocks
@@ -639,8 +638,8 @@ __device__ __forceinline__ void lev2_path(const PathSet& ps, u32 p, const u64* _
             if (mine) {
                 const u32 rows = min(64u, nq - blk * 64);
                 u32 h0, l0, h1 = 0, l1 = 0;
-                code_planes32(window32(ps.words, pb + (u64)blk * 64), &h0, &l0);
-                if (rows > 32) code_planes32(window32(ps.words, pb + (u64)blk * 64 + 32), &h1, &l1);
+                code_planes32(window32(qwords, pb + (u64)blk * 64), &h0, &l0);
+                if (rows > 32) code_planes32(window32(qwords, pb + (u64)blk * 64 + 32), &h1, &l1);
                 H = (u64)h0 | ((u64)h1 << 32);
                 Lo = (u64)l0 | ((u64)l1 << 32);
                 valid = rows == 64 ? ~0ull : ((1ull << rows) - 1);
@@ -664,7 +663,7 @@ __device__ __forceinline__ void lev2_path(const PathSet& ps, u32 p, const u64* _
             else if (ln == 0 && (s0 >> 6) <= q_last) { const uint4 c = carry[s0 >> 6]; wp0 = c.x; wp1 = c.y; wn0 = c.z; wn1 = c.w; }
             if (s0 >= 64 && s0 + 64 <= nt) {
                 // ---- every lane is inside its band for all 64 columns of this chunk; the lane's columns are s0 - ln .. s0 - ln + 63
-                const u64 W0 = window32(twords, (u64)(s0 - ln)), W1 = window32(twords, (u64)(s0 - ln) + 32);
+                const u64 W0 = window32(twords, tb0 + (u64)(s0 - ln)), W1 = window32(twords, tb0 + (u64)(s0 - ln) + 32);
                 const u32 w[4] = {(u32)(W0 >> 32), (u32)W0, (u32)(W1 >> 32), (u32)W1};
                 if (last_band) {
                     static_for<64>([&](auto T) {
@@ -686,7 +685,8 @@ __device__ __forceinline__ void lev2_path(const PathSet& ps, u32 p, const u64* _
                 for (u32 t = 0; t < steps; ++t) {
                     const u32 j = s0 + t - ln;            // (wraps for s < ln: not active)
                     const bool act = mine && j < nt;
-                    const u32 base = act ? (u32)(twords[j >> 5] >> (62 - 2 * (j & 31))) & 3u : 0u;
+                    const u64 tj = tb0 + j;
+                    const u32 base = act ? (u32)(twords[tj >> 5] >> (62 - 2 * (u32)(tj & 31))) & 3u : 0u;
                     lev2_step<true, true, INFIX>(L, lmask[base * 64 + ln], (t < 32 ? wp0 : wp1) << (t & 31), (t < 32 ? wn0 : wn1) << (t & 31), act);
                     if (t == 30) { snap_p = L.cp; snap_n = L.cn; }
                     if (!last_band && t == 62 && s0 >= 64 && ln == 63) carry[(s0 >> 6) - 1] = make_uint4(snap_p, L.cp, snap_n, L.cn);
@@ -703,7 +703,7 @@ __device__ __forceinline__ void lev2_path(const PathSet& ps, u32 p, const u64* _
         for (int o = 32; o; o >>= 1) sc += __shfl_xor(sc, o, 64);
         sc += (int)nt;
     }
-    if (ln == 0) out[p] = (int32_t)sc;
+    if (ln == 0) *out_p = (int32_t)sc;
 }
 
 #ifndef GASM_LEV2_EU
@@ -716,8 +716,15 @@ __global__ void __launch_bounds__(GASM_WG) __attribute__((amdgpu_waves_per_eu(GA
     uint4* const carry = carry_ws + (u64)wave * carry_stride;         // (nt - 1) / 64 + 1 groups of this wave
     u64* const lmask = s_mask[threadIdx.x >> 6];
     for (u32 p = wave; p < n_paths; p += n_waves) {
-        if (infix) lev2_path<true>(ps, p, twords, nt, carry, lmask, out);
-        else lev2_path<false>(ps, p, twords, nt, carry, lmask, out);
+        const u64 pb = ps.p_off[p];
+        const u32 nq = (u32)(ps.p_off[p + 1] - pb);
+        if (nq == 0 || nt == 0) { if ((threadIdx.x & 63) == 0) out[p] = 0; continue; }     // edlib reports an error, the reference returns 0
+        if (infix) { lev2_path<true>(ps.words, pb, nq, twords, 0, nt, carry, lmask, out + p); continue; }
+        // the global distance is symmetric: whichever of the two strings makes the fuller bands gives the rows (a band is 64
+        // lanes x 64 rows whatever is left for the last one; 17 kb against 50 kb: 5 bands x 50 k columns or 13 x 17 k: 11 % fewer steps)
+        const u64 cost_q = (u64)((((nq + 63) >> 6) + 63) >> 6) * ((u64)nt + 63), cost_t = (u64)((((nt + 63) >> 6) + 63) >> 6) * ((u64)nq + 63);
+        if (cost_t < cost_q) lev2_path<false>(twords, 0, nt, ps.words, pb, nq, carry, lmask, out + p);
+        else lev2_path<false>(ps.words, pb, nq, twords, 0, nt, carry, lmask, out + p);
     }
 }
 

@@ -1099,13 +1099,16 @@ int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 ta
     // a wave per path, in the order of the paths (scaffolds come longest first): the dispatcher hands the next workgroup to
     // the CU that has room, which balances better than a fixed share of paths per resident wave (22 053 scaffolds of one
     // segment: 329 -> 318 ms); what a wave parks for its next band is 16 bytes per 64 target columns, capped at 2 GB in all
-    const u64 per_wave = (((u64)target_len - 1) / 64 + 2) * 16;
+    // (global distances may run with the roles of path and target swapped: the columns are then the path's)
+    u64 max_cols = target_len;
+    if (!infix) for (u32 p = 0; p < P; ++p) max_cols = std::max<u64>(max_cols, dp.h_p_off[p + 1] - dp.h_p_off[p]);
+    const u64 per_wave = ((max_cols - 1) / 64 + 2) * 16;
     const u32 cap = (u32)std::max<u64>((u64)ctx->n_cu * 32u, std::min<u64>(1u << 20, (2ull << 30) / per_wave));
     const u32 waves = std::min<u32>(P, getenv("GASM_LEV_WAVES") ? (u32)ctx->n_cu * (u32)atoi(getenv("GASM_LEV_WAVES")) : cap);
     const u32 wgs = (waves + GASM_WG / 64 - 1) / (GASM_WG / 64);
     const bool v2 = env_int("GASM_LEV_V", 2) != 1;
     // what a band leaves for the next one, per wave: 16 bytes per 64 target columns (v2) / a byte per column
-    const u64 stride = v2 ? ((target_len - 1) / 64 + 2) : ((target_len + 64 + 63) & ~(u64)63);
+    const u64 stride = v2 ? ((max_cols - 1) / 64 + 2) : ((target_len + 64 + 63) & ~(u64)63);
     st = carry.ensure((size_t)wgs * (GASM_WG / 64) * stride * (v2 ? 16 : 1));
     if (st == GASM_OK) st = d_out.ensure((size_t)P * 4);
     if (st == GASM_OK) {
