@@ -111,6 +111,11 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args))
 
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)          # stdout proper is kept for the JSON line; fd 1 is stderr from here on (all ranks)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -181,17 +186,7 @@ def main():
         uid = [pooled.Comm.unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
-        # ncclCommInitRank: also at N = 1, so the one-GPU box runs the RCCL path.  This RCCL prints its version banner on
-        # stdout when a communicator comes up; stdout is the one JSON line's, so the banner goes to stderr.
-        sys.stdout.flush()
-        keep_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            comm = pooled.Comm.rccl(ctx, uid[0], rank, world)
-        finally:
-            sys.stdout.flush()
-            os.dup2(keep_fd, 1)
-            os.close(keep_fd)
+        comm = pooled.Comm.rccl(ctx, uid[0], rank, world)       # ncclCommInitRank: also at N = 1, so the one-GPU box runs the RCCL path
         state = {}
         n_km = int(off[-1]) * (rl - k + 1)
 
@@ -510,7 +505,13 @@ def _print_line(args, world, nseg, L, rl, cov, k, n_kmers, n_reads, n_distinct, 
         out["pooled"] = pooled_info
     if breakdown:
         out["kernel_ms_per_step"] = breakdown
-    print(json.dumps(out), flush=True)
+    # the ONE line goes to the stdout this process was started with; everything else that writes to file descriptor 1
+    # (Gloo's "connected to N peer ranks", RCCL's version banner, whatever a library prints) has been sent to stderr
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(out) + "\n").encode())
+
+
+_REAL_STDOUT = None
 
 
 if __name__ == "__main__":
