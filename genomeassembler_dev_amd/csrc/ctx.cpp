@@ -71,17 +71,35 @@ void gasm_ctx::prof_end(int stage, hipEvent_t a, hipEvent_t b) {
     pending.push_back({stage, a, b});
 }
 
+// GASM_PROF_TIMELINE=<file> (diagnostic): every profiled launch as "stream name start_ms end_ms" relative to the first event
+// this process collected — the steps' real timeline across the streams of the step slots, without a tracer that spaces the
+// dispatches out (tools/slot_timeline.py)
+static hipEvent_t g_tl_base = nullptr;
+static FILE* timeline_file() {
+    static FILE* f = [] { const char* v = getenv("GASM_PROF_TIMELINE"); return v && *v ? fopen(v, "w") : (FILE*)nullptr; }();
+    return f;
+}
+
 int gasm_ctx::prof_collect() {
     HIPCHK(hipStreamSynchronize(stream));
+    FILE* const tl = pending.empty() ? nullptr : timeline_file();
+    if (tl && !g_tl_base) g_tl_base = pending.front().a;          // (kept: never returned to the pool)
     for (auto& p : pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             stages[p.stage].ms += ms;
             stages[p.stage].launches += 1;
         }
+        if (tl) {
+            float t0 = 0, t1 = 0;
+            if (hipEventElapsedTime(&t0, g_tl_base, p.a) == hipSuccess && hipEventElapsedTime(&t1, g_tl_base, p.b) == hipSuccess)
+                fprintf(tl, "%p %s %.4f %.4f\n", (void*)stream, stages[p.stage].name.c_str(), t0, t1);
+        }
+        if (p.a == g_tl_base) { ev_pool.push_back(p.b); continue; }
         ev_pool.push_back(p.a);
         ev_pool.push_back(p.b);
     }
+    if (tl) fflush(tl);
     pending.clear();
     return GASM_OK;
 }
