@@ -1103,7 +1103,7 @@ int pipeline_levenshtein(gasm_ctx* ctx, DevPaths& dp, const char* target, u64 ta
     u64 max_cols = target_len;
     if (!infix) for (u32 p = 0; p < P; ++p) max_cols = std::max<u64>(max_cols, dp.h_p_off[p + 1] - dp.h_p_off[p]);
     const u64 per_wave = ((max_cols - 1) / 64 + 2) * 16;
-    const u32 cap = (u32)std::max<u64>((u64)ctx->n_cu * 32u, std::min<u64>(1u << 20, (2ull << 30) / per_wave));
+    const u32 cap = (u32)std::max<u64>((u64)ctx->n_cu * 4u, std::min<u64>(1u << 20, (2ull << 30) / per_wave));      // (at least a wave per SIMD)
     const u32 waves = std::min<u32>(P, getenv("GASM_LEV_WAVES") ? (u32)ctx->n_cu * (u32)atoi(getenv("GASM_LEV_WAVES")) : cap);
     const u32 wgs = (waves + GASM_WG / 64 - 1) / (GASM_WG / 64);
     const bool v2 = env_int("GASM_LEV_V", 2) != 1;
