@@ -358,6 +358,7 @@ int guided_build(gasm_ctx* ctx, DevReads& rd, BuildState& bs, DevPaths& cp, Scor
     GCHK(d_prev.ensure(std::max<u32>(P, 1) * 4));
     const size_t fx_off = (cs.stride * 4 + 15) & ~(size_t)15;
     const unsigned long long* d_fx = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(cs.d_total.p) + fx_off);
+    AsmLap lap;
     GLAUNCH(ctx, "k_guided_chain", k_guided_chain, dim3(S), dim3(64), (size_t)max_c + 16, cp.view(), d_fx, k, d_next.as<u32>(), d_prev.as<u32>());
     std::vector<u32> next(P), prev(P);
     if (P) {
@@ -365,10 +366,12 @@ int guided_build(gasm_ctx* ctx, DevReads& rd, BuildState& bs, DevPaths& cp, Scor
         HIPCHK(hipMemcpyAsync(prev.data(), d_prev.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    lap(ctx, "guided: chain kernel + links back");
     // ---- chains -> scaffolds, per segment by descending length, ties by first contig (= lexicographic: contigs are sorted
     // and begin with distinct k-mers)
     std::vector<u64> clen(P);
     GCHK(pipeline_fetch_contigs(ctx, rd, bs));
+    lap(ctx, "guided: contigs fetched");
     for (u32 c = 0; c < P; ++c) clen[c] = bs.h_c_off[c + 1] - bs.h_c_off[c];
     ChainCsr csr;
     csr.clear();
@@ -397,6 +400,7 @@ int guided_build(gasm_ctx* ctx, DevReads& rd, BuildState& bs, DevPaths& cp, Scor
         g.h_seg_off[s + 1] = csr.sig_off.size() - 1;
     }
     const u32 G = (u32)(csr.sig_off.size() - 1);
+    lap(ctx, "guided: chains -> CSR (host)");
     DevPaths& dp = g.dp;
     dp.n_segments = S; dp.n_paths = G;
     dp.b_p_off = nullptr; dp.b_seg_path_off = nullptr; dp.b_seg_base_off = nullptr;
@@ -408,8 +412,11 @@ int guided_build(gasm_ctx* ctx, DevReads& rd, BuildState& bs, DevPaths& cp, Scor
     // contigs are packed already (the scorer's copy) with their offsets on the device
     GCHK(expand(ctx, csr, cp.d_words.as<u64>(), bs.d_c_off.as<u64>(), dp.d_words, tmp));
     GCHK(dp.upload_dirs(ctx));
+    lap(ctx, "guided: expand + directories");
     GCHK(pipeline_score_launch(ctx, rd, dp, kmer, tb, false, false, g.ss, nullptr));
+    lap(ctx, "guided: scoring launched");
     GCHK(pipeline_score_fetch(ctx, g.ss));
+    lap(ctx, "guided: scores fetched");
     g.h_text.clear(); g.h_text_off.clear();
     g.valid = true;
     return GASM_OK;
