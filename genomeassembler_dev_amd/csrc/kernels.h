@@ -91,8 +91,6 @@ __global__ void k_pack_ascii(const u8* ascii, u64 nbases_host, const u64* nbases
 template <class K> __global__ void k_tile_hist(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 n_tiles, ushort4* tcnt);
 __global__ void k_tile_scan(ReadSet rs, int bbits, u32 padm, const ushort4* tcnt, u32* toff, u32* hist, u32* flags);
 template <class TO> __global__ void k_scan_excl(const u32* in, TO* out, u32 n);
-__global__ void k_seg_offsets(const u32* seg_ncontig, const u64* seg_cbases, u32 S, u32* seg_cstart, u64* seg_bstart, const u32* dstart, u32 nb,
-                              const u32* flags, u32* report, u32 ticket);
 __global__ void k_copy_u64(const u64* a, u64* b, u32 n);
 template <class K>
 __global__ void k_bucket_scatter(ReadSet rs, const uint4* tinfo, int k, int bbits, u32 g, u32 padm, u32 n_tiles, const u64* bstart, const u32* toff,
@@ -103,7 +101,7 @@ __global__ void k_bucket_partition(ReadSet rs, const uint4* tinfo, int k, int bb
                                    K* keys, u64 scratch, u32* flags);
 template <class K, int TBL>
 __global__ void k_bucket_dedup(K* keys, u32* mult, const u64* bstart, const u32* blen, u32* bucket_d, u32* overflow, u16* fdir, int low_bits, int dbg,
-                               unsigned long long* stamps);
+                               unsigned long long* stamps, u32* dstart);
 #define GASM_BUCKET_MAX 65535   // distinct keys of one bucket (16-bit fine directory)
 template <class K>
 __global__ void k_bucket_dedup_multi(const K* keys, K* keys_out, u32* mult, const u64* bstart, u32* bucket_d, u32* overflow, u16* fdir, int low_bits);
@@ -121,7 +119,7 @@ __global__ void k_rank_rulers(GraphView gv, u32 n_segments, u32 chunks, u64* lin
 __global__ void k_rank_lds(GraphView gv, const u32* rtab, u64* link, int max_rounds, u32 rshift, u32 lds_entries, u32* flags);
 __global__ void k_chain_len(const u32* nxt, const u64* link, u32* clen, const u32* n_edges_p);
 __global__ void k_contig_scan(GraphView gv, const u8* eflag, const u32* clen, u32* e_cid, u64* e_coff, u32* seg_ncontig,
-                              u64* seg_cbases);
+                              u64* seg_cbases, u32* done, u32* seg_cstart, u64* seg_bstart, const u32* flags, u32* report, u32 ticket);
 __global__ void k_contig_place(GraphView gv, const u8* eflag, const u32* seg_cstart, const u64* seg_bstart, u32* e_cid, u64* e_coff,
                                u64* c_off, u32 n_segments, u32 chunks);
 template <class K>

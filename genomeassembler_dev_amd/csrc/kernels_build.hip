@@ -18,7 +18,7 @@
 //                     the walk itself as list ranking (the reference walks node by node): every second edge ranked by
 //                     pointer doubling inside LDS, the rest finished by a step or two; whole-GPU doubling for
 //                     segments of more than 65534 edges
-//   k_chain_len / k_contig_scan / k_seg_offsets / k_contig_place / k_contig_emit
+//   k_chain_len / k_contig_scan (+ seg_offsets_wave: directories and report) / k_contig_place / k_contig_emit
 //                     lib/DeNovoAssembler.cpp:183-192: contig text, in sorted order (contigs start with distinct
 //                     k-mers, so sorting contigs = sorting their first edges)
 #include "device_utils.h"
@@ -243,20 +243,22 @@ template __global__ void k_scan_excl<u32>(const u32*, u32*, u32);
 //   report[2S+2 .. 4S+3]      first contig base of every segment (+ the total), (lo, hi) pairs
 //   report[4S+4]              flags[0]: a bucket overflowed its table        report[4S+5]  flags[1]: list ranking gave up
 //   report[4S+6]              ticket
-__global__ void __launch_bounds__(64) k_seg_offsets(const u32* __restrict__ seg_ncontig, const u64* __restrict__ seg_cbases, u32 S,
-                                                    u32* __restrict__ seg_cstart, u64* __restrict__ seg_bstart,
-                                                    const u32* __restrict__ dstart, u32 nb, const u32* __restrict__ flags,
-                                                    u32* __restrict__ report, u32 ticket) {
+// (body: one wave; `seg_ncontig` / `seg_cbases` are read with agent-scope loads — in k_contig_scan's last workgroup they come
+// from workgroups of other XCDs, whose L2 this one does not share)
+__device__ __forceinline__ void seg_offsets_wave(const u32* __restrict__ seg_ncontig, const u64* __restrict__ seg_cbases, u32 S,
+                                                 u32* __restrict__ seg_cstart, u64* __restrict__ seg_bstart,
+                                                 const u32* __restrict__ dstart, u32 nb, const u32* __restrict__ flags,
+                                                 u32* __restrict__ report, u32 ticket) {
     // one wave, 64 segments at a time (a batch rarely has more than a few hundred segments)
-    const u32 ln = threadIdx.x;
+    const u32 ln = threadIdx.x & 63;
     u32 ccarry = 0;
     u64 bcarry = 0;
     u32* const rc = report + S + 1;
     u32* const rb = report + 2 * S + 2;
     for (u32 base = 0; base < S; base += 64) {
         const u32 i = base + ln;
-        const u32 c = i < S ? seg_ncontig[i] : 0u;
-        const u64 b = i < S ? seg_cbases[i] : 0ull;
+        const u32 c = i < S ? __hip_atomic_load(&seg_ncontig[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const u64 b = i < S ? __hip_atomic_load(&seg_cbases[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
         const u32 cinc = wave_incl_scan(c);
         u64 binc = b;
 #pragma unroll
@@ -685,10 +687,48 @@ __device__ __forceinline__ bool dedup_step(K128* t_key, u32* t_cnt, u32* n_disti
 #ifndef GASM_DEDUP_WGS
 #define GASM_DEDUP_WGS 6
 #endif
+// "Last workgroup done" without a release fence.  An agent-scope release (__threadfence) on this part writes back EVERY dirty
+// line of the XCD's L2 (buffer_wbl2) — with the de-duplication's 6 400 workgroups and an L2 full of freshly written keys that
+// took the kernel from 0.38 to 0.63 ms (measured; round 3).  What the last workgroup needs from the others is one word each,
+// so that word is published by an agent-scope atomic store (written through, sc1), the thread waits for the store to complete
+// (s_waitcnt: the recipe of the memory model's release minus the write-back that only plain stores need) and then counts
+// itself in with a relaxed atomic; the reader uses agent-scope atomic loads.  Returns true in the workgroup that came last.
+__device__ __forceinline__ void publish_u32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void publish_u64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool count_in_last(u32* done) {       // (by the thread that published)
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+}
+
+// The last workgroup of a de-duplication launch to get here turns the buckets' distinct counts into `dstart` — what
+// k_scan_excl<u32> did in a launch of its own (one workgroup, 8 us of work that waited 15-65 us for a slot on a chip shared
+// with the other steps' kernels).  `done`: a zeroed flag word of the build.  s_word: one LDS word; thread 0 has published
+// bucket_d[blockIdx.x] (publish_u32) before the call.
+__device__ __forceinline__ void dedup_last_scan(const u32* __restrict__ bucket_d, u32* __restrict__ dstart, u32 n, u32* __restrict__ done, u32* s_word,
+                                                u32* s_waves /* GASM_WG / 64 words */) {
+    if (!dstart) return;
+    __syncthreads();                                                // (the LDS words are free from here on)
+    if (threadIdx.x == 0) *s_word = count_in_last(done) ? 1u : 0u;
+    __syncthreads();
+    if (!*s_word) return;
+    const u32 per = (n + GASM_WG - 1) / GASM_WG, a = min(n, threadIdx.x * per), b = min(n, a + per);
+    u32 sum = 0;
+    for (u32 i = a; i < b; ++i) sum += __hip_atomic_load(&bucket_d[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 inc = wave_incl_scan(sum);
+    __syncthreads();                                                // (s_word has been read by everybody)
+    if ((threadIdx.x & 63) == 63) s_waves[threadIdx.x >> 6] = inc;
+    __syncthreads();
+    u32 ex = inc - sum, tot = 0;
+    for (u32 w = 0; w < GASM_WG / 64; ++w) { const u32 t = s_waves[w]; if (w < (threadIdx.x >> 6)) ex += t; tot += t; }
+    for (u32 i = a; i < b; ++i) { dstart[i] = ex; ex += __hip_atomic_load(&bucket_d[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (threadIdx.x == 0) dstart[n] = tot;
+}
+
 template <class K, int TBL>
 __global__ void __launch_bounds__(GASM_WG, TBL == 4096 ? 3 : sizeof(K) == 8 ? GASM_DEDUP_WGS : 4)
 k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restrict__ bstart, const u32* __restrict__ blen, u32* __restrict__ bucket_d,
-               u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg, unsigned long long* __restrict__ stamps) {
+               u32* __restrict__ overflow, u16* __restrict__ fdir, int low_bits, int dbg, unsigned long long* __restrict__ stamps,
+               u32* __restrict__ dstart) {
     constexpr int LIMIT = TBL / 16 * 11;
     constexpr int BINS = TBL / 4;
     constexpr int LOG_TBL = TBL == 4096 ? 12 : 11;
@@ -732,7 +772,8 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
         const u64 len = blen[bucket];
         if (len > n) {
             for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)bucket * (BINS + 1) + i] = 0;
-            if (threadIdx.x == 0) bucket_d[bucket] = 0;
+            if (threadIdx.x == 0) publish_u32(&bucket_d[bucket], 0u);
+            dedup_last_scan(bucket_d, dstart, gridDim.x, overflow + 8, s_tmp + 7, s_tmp);
             return;
         }
         n = len;
@@ -866,21 +907,23 @@ k_bucket_dedup(K* __restrict__ keys, u32* __restrict__ mult, const u64* __restri
         // kernels of THIS attempt run (pipeline_build_finish), so the bucket must be left empty AND searchable: an all-zero
         // fine directory (graph_lower_bound would otherwise bisect between whatever the allocation held)
         for (u32 i = threadIdx.x; i <= (u32)BINS; i += GASM_WG) fdir[(u64)bucket * (BINS + 1) + i] = 0;
-        if (threadIdx.x == 0) { atomicOr(overflow, 1u); bucket_d[bucket] = 0; }
+        if (threadIdx.x == 0) { atomicOr(overflow, 1u); publish_u32(&bucket_d[bucket], 0u); }
+        dedup_last_scan(bucket_d, dstart, gridDim.x, overflow + 8, s_tmp + 7, s_tmp);
         return;
     }
     const u32 d = *w_distinct;
-    if ((dbg & 3) == 1 || (dbg & 3) == 2) { if (threadIdx.x == 0) bucket_d[bucket] = d; return; }
+    if ((dbg & 3) == 1 || (dbg & 3) == 2) { if (threadIdx.x == 0) publish_u32(&bucket_d[bucket], d); dedup_last_scan(bucket_d, dstart, gridDim.x, overflow + 8, s_tmp + 7, s_tmp); return; }
     dedup_order<K, TBL, true>(t_key, t_cnt, s_start, s_cur, s_tmp, fdir, bucket, low_bits, d);
     phase(4);
     for (u32 i = threadIdx.x; i < d; i += GASM_WG) { keys[beg + i] = t_key[i]; mult[beg + i] = t_cnt[i]; }
-    if (threadIdx.x == 0) bucket_d[bucket] = d;
+    if (threadIdx.x == 0) publish_u32(&bucket_d[bucket], d);
     phase(5);
     if (stamps && threadIdx.x == 0) stamps[8 + 3 * (u64)blockIdx.x + 1] = wall_clock64();
+    dedup_last_scan(bucket_d, dstart, gridDim.x, overflow + 8, s_tmp + 7, s_tmp);
 }
-template __global__ void k_bucket_dedup<u64, 4096>(u64*, u32*, const u64*, const u32*, u32*, u32*, u16*, int, int, unsigned long long*);
-template __global__ void k_bucket_dedup<u64, 2048>(u64*, u32*, const u64*, const u32*, u32*, u32*, u16*, int, int, unsigned long long*);
-template __global__ void k_bucket_dedup<K128, 2048>(K128*, u32*, const u64*, const u32*, u32*, u32*, u16*, int, int, unsigned long long*);
+template __global__ void k_bucket_dedup<u64, 4096>(u64*, u32*, const u64*, const u32*, u32*, u32*, u16*, int, int, unsigned long long*, u32*);
+template __global__ void k_bucket_dedup<u64, 2048>(u64*, u32*, const u64*, const u32*, u32*, u32*, u16*, int, int, unsigned long long*, u32*);
+template __global__ void k_bucket_dedup<K128, 2048>(K128*, u32*, const u64*, const u32*, u32*, u32*, u16*, int, int, unsigned long long*, u32*);
 
 // ================================================================================================================
 // De-duplication of buckets that no table can hold (the last rung of pipeline_build_finish's ladder: ten bucket bits and
@@ -1308,9 +1351,15 @@ __global__ void __launch_bounds__(GASM_WG) k_chain_len(const u32* __restrict__ n
 // (contig length = k-1 + chain length).  One workgroup of 1024 threads per segment; each of the 16 waves owns a
 // contiguous sixteenth of the edges and scans it on its own (DPP scans with a running carry, no barriers), the wave
 // totals meet once in LDS, and a second sweep adds the offsets.
+// Round 3: the segment directories and the build's report (k_seg_offsets, a launch of one wave) are the job of the LAST
+// workgroup to finish — beside other steps' streaming kernels every dependent launch waits for a slot on the chip, and this
+// one was 5 us of work behind 15-60 us of waiting.  `done`: a zeroed flag word of the build (k_bucket_gather zeroes it).
 __global__ void __launch_bounds__(1024) k_contig_scan(GraphView gv, const u8* __restrict__ eflag, const u32* __restrict__ clen,
                                                       u32* __restrict__ e_cid, u64* __restrict__ e_coff,
-                                                      u32* __restrict__ seg_ncontig, u64* __restrict__ seg_cbases) {
+                                                      u32* __restrict__ seg_ncontig, u64* __restrict__ seg_cbases,
+                                                      u32* __restrict__ done, u32* __restrict__ seg_cstart, u64* __restrict__ seg_bstart,
+                                                      const u32* __restrict__ flags, u32* __restrict__ report, u32 ticket) {
+    __shared__ u32 s_last;
     __shared__ u32 s_cnt[16];
     __shared__ u64 s_bas[16];
     const u32 seg = blockIdx.x;
@@ -1365,7 +1414,13 @@ __global__ void __launch_bounds__(1024) k_contig_scan(GraphView gv, const u8* __
                 if (ef[q] & 1) { e_cid[base + 64 * q] += cbefore; e_coff[base + 64 * q] += bbefore; }
         }
     }
-    if (threadIdx.x == 0) { seg_ncontig[seg] = ctot; seg_cbases[seg] = btot; }
+    if (threadIdx.x == 0) {
+        publish_u32(&seg_ncontig[seg], ctot); publish_u64(&seg_cbases[seg], btot);      // (no release fence: see count_in_last)
+        s_last = count_in_last(done) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last || wv) return;
+    seg_offsets_wave(seg_ncontig, seg_cbases, gridDim.x, seg_cstart, seg_bstart, gv.dstart, nb, flags, report, ticket);
 }
 
 // Heads: make contig ids and offsets global; record offset and length per contig.

@@ -603,6 +603,10 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
         d_stamps = stamp_buf.as<unsigned long long>();
     }
     const int dbg_d = knobs().dbg_dedup | (knobs().dedup_warm << 2);
+    // the buckets' distinct counts -> dstart by the de-duplication's last workgroup (a word of the build's zeroed flags counts
+    // the finished ones); beyond 16 384 buckets one workgroup of 256 is too slow a scanner: k_scan_excl in a launch of its own
+    const bool scan_in_dedup = !bs.multi_pass && nbt <= 16384 && env_int("GASM_SCAN_IN_DEDUP", 1) != 0;
+    u32* const d_scan_out = scan_in_dedup ? bs.d_dstart.as<u32>() : nullptr;
     bs.fbits = (bs.small_tbl && !bs.multi_pass) ? 9 : 10;   // bins of the de-duplication kernel's counting sort = TBL / 4 (the multi-pass kernel: 4096 slots)
     GCHK(bs.d_fdir.ensure((size_t)nbt * ((1u << bs.fbits) + 1) * 2));
     // (k_bucket_dedup writes every entry of its bucket's fine directory)
@@ -617,13 +621,13 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
         HIPCHK(hipMemcpyAsync(bs.d_keys.p, bs.d_keys2.p, n_alloc * KB, hipMemcpyDeviceToDevice, ctx->stream));
     } else if (W == 2) {
         GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<K128, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<K128>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), d_blen, bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+                bs.d_bstart.as<u64>(), d_blen, bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps, d_scan_out);
     } else if (bs.small_tbl) {
         GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 2048>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), d_blen, bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+                bs.d_bstart.as<u64>(), d_blen, bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps, d_scan_out);
     } else {
         GLAUNCH(ctx, "k_bucket_dedup", (k_bucket_dedup<u64, 4096>), dim3(nbt), dim3(GASM_WG), 0, bs.d_keys.as<u64>(), bs.d_mult.as<u32>(),
-                bs.d_bstart.as<u64>(), d_blen, bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps);
+                bs.d_bstart.as<u64>(), d_blen, bs.d_bucket_d.as<u32>(), bs.d_flags.as<u32>(), bs.d_fdir.as<u16>(), 2 * k - bbits, dbg_d, d_stamps, d_scan_out);
     }
     if (d_stamps) {
         std::vector<unsigned long long> hv(8 + (size_t)nbt * 3);
@@ -634,7 +638,7 @@ int launch_distinct(gasm_ctx* ctx, DevReads& rd, BuildState& bs) {
         fprintf(stderr, "[dedup stamps, 100 MHz ticks per workgroup] init %.1f  first-iter %.1f  stream %.1f  barrier %.1f  order %.1f  writeback %.1f\n",
                 (double)h[0] / nbt, (double)h[1] / nbt, (double)h[2] / nbt, (double)h[3] / nbt, (double)h[4] / nbt, (double)h[5] / nbt);
     }
-    GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt);
+    if (!scan_in_dedup) GLAUNCH(ctx, "k_scan_excl", k_scan_excl<u32>, dim3(1), dim3(1024), 0, bs.d_bucket_d.as<u32>(), bs.d_dstart.as<u32>(), nbt);
     return GASM_OK;
 }
 
@@ -741,9 +745,7 @@ static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
     if (!bs.ranked_in_lds)      // (the LDS path's k_link_jump launches publish the chains' lengths themselves)
         GLAUNCH(ctx, "k_chain_len", k_chain_len, dim3(std::max(1u, grid_all)), dim3(GASM_WG), 0, bs.d_nxt.as<u32>(), bs.d_link.as<u64>(),
                 bs.d_clen.as<u32>(), gv.dstart + (size_t)S * nb);
-    GLAUNCH(ctx, "k_contig_scan", k_contig_scan, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
-            bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), d_seg_ncontig, bs.d_seg_cbases.as<u64>());
-    // segment directories of the contigs + the report (ticket last)
+    // segment directories of the contigs + the report (ticket last): written by the last workgroup of k_contig_scan to finish
     const size_t words = 4 * (size_t)S + 8;
     if (bs.h_report_words < words) {
         if (bs.h_report) (void)hipHostFree(bs.h_report);
@@ -753,8 +755,9 @@ static int launch_graph_dense(gasm_ctx* ctx, u32 S, BuildState& bs) {
     }
     bs.ticket = next_ticket();
     reinterpret_cast<volatile u32*>(bs.h_report)[4 * (size_t)S + 6] = 0;     // (the report of the previous build has been read or is void)
-    GLAUNCH(ctx, "k_seg_offsets", k_seg_offsets, dim3(1), dim3(64), 0, d_seg_ncontig, bs.d_seg_cbases.as<u64>(), S, bs.d_seg_cstart.as<u32>(),
-            bs.d_seg_bstart.as<u64>(), gv.dstart, nb, d_fl, bs.h_report, bs.ticket);
+    GLAUNCH(ctx, "k_contig_scan", k_contig_scan, dim3(S), dim3(1024), 0, gv, bs.d_eflag.as<u8>(), bs.d_clen.as<u32>(),
+            bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), d_seg_ncontig, bs.d_seg_cbases.as<u64>(), d_fl + 9, bs.d_seg_cstart.as<u32>(),
+            bs.d_seg_bstart.as<u64>(), d_fl, bs.h_report, bs.ticket);
     GLAUNCH(ctx, "k_contig_place", k_contig_place, grid_seg, dim3(GASM_WG), 0, gv, bs.d_eflag.as<u8>(),
             bs.d_seg_cstart.as<u32>(), bs.d_seg_bstart.as<u64>(), bs.d_ecid.as<u32>(), bs.d_ecoff.as<u64>(), bs.d_c_off.as<u64>(), S, dchunks);
     if (W == 1) {
