@@ -1,5 +1,10 @@
-import os, sys, time
-sys.path.insert(0, "/root/repo")
+"""Host time to QUEUE a step (build + score of cfg2) against the time the GPU needs for it: the host runs far ahead.
+usage: python tools/enqueue_cost.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import genomeassembler_dev_amd as ga
 from genomeassembler_dev_amd import qtable, synth
 reads, seg_off, _g = synth.make_batch(100, 50000, 150, 50, seed0=1234, planted=True)
