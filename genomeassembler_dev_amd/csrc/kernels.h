@@ -149,7 +149,7 @@ __global__ void k_str_bitonic(const u64* words, const u64* off, u32* idx, u32 n_
 __global__ void k_str_bitonic_block(const u64* words, const u64* off, u32* idx, u32 n_pow2, u32 kk, u32 j0, ChainSigs cs);
 __global__ void k_str_adjacent_eq(const u64* words, const u64* off, const u32* idx, u32 n, u8* same_as_prev, ChainSigs cs);
 __global__ void k_unpack_ascii(const u64* words, u64 nbases, u8* out);
-__global__ void k_guided_chain(PathSet ps, const unsigned long long* fx, int k, u32* g_next, u32* g_prev);
+__global__ void k_guided_chain(PathSet ps, const unsigned long long* fx, int k, u32* g_next, u32* g_prev, u32* dbg_order);
 __global__ void k_asm_match(const u64* cwords, const u64* c_off, u32 n, int k, u8* match, u8* row_any, u8* level_any);
 __global__ void k_asm_merge(const u32* perm, u32 rows, u32 n, int k, const u32* clen, const u8* match, const u8* row_any, const u8* level_any,
                             const u64* cwords, const u64* c_off, u32* out_next, u8* out_ov, u32* out_heads, u32* out_nchains, u8* need_host);

@@ -272,11 +272,12 @@ struct GBest { unsigned long long fs; u32 len; u32 idx; };
 __device__ __forceinline__ bool gbest_better(const GBest& a, const GBest& b) {          // a before b?
     if (b.idx == GASM_NONE32) return a.idx != GASM_NONE32;
     if (a.idx == GASM_NONE32) return false;
-    // a.fs / a.len > b.fs / b.len  <=>  a.fs * b.len > b.fs * a.len   (128-bit products)
-    const unsigned long long al = a.fs * (unsigned long long)b.len, ah = __umul64hi(a.fs, (unsigned long long)b.len);
-    const unsigned long long bl = b.fs * (unsigned long long)a.len, bh = __umul64hi(b.fs, (unsigned long long)a.len);
-    if (ah != bh) return ah > bh;
-    if (al != bl) return al > bl;
+    // a.fs / a.len > b.fs / b.len  <=>  a.fs * b.len > b.fs * a.len, in 128 bits.  (Round 2 spelled this with two __umul64hi
+    // and two 64-bit products; inside this kernel that form chose wrong seeds whenever the sums had 50+ bits — 843 of 20 338
+    // random segments of tools/soak_guided.py, none with this form; the same comparator in a kernel of its own
+    // (tools/micro/mulhi_test2.hip) is right, so the spelling is not what was wrong, the code generated for it here was.)
+    const unsigned __int128 pa = (unsigned __int128)a.fs * b.len, pb = (unsigned __int128)b.fs * a.len;
+    if (pa != pb) return pa > pb;
     return a.idx < b.idx;
 }
 __device__ __forceinline__ GBest gbest_wave(GBest v) {
@@ -300,7 +301,7 @@ __device__ __forceinline__ bool bases_eq_short(const u64* __restrict__ w, u64 p,
 }
 
 __global__ void __launch_bounds__(64) k_guided_chain(PathSet ps, const unsigned long long* __restrict__ fx, int k, u32* __restrict__ g_next,
-                                                     u32* __restrict__ g_prev) {
+                                                     u32* __restrict__ g_prev, u32* __restrict__ dbg_order) {
     extern __shared__ u8 s_used[];
     const u32 seg = blockIdx.x, lane = threadIdx.x;
     const u32 c0 = ps.seg_path_off[seg], n = ps.seg_path_off[seg + 1] - c0;
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(64) k_guided_chain(PathSet ps, const unsigned 
     for (;;) {
         const GBest seed = best_of(0, 0);
         if (seed.idx == GASM_NONE32) break;
-        if (lane == 0) s_used[seed.idx] = 1;
+        if (lane == 0) { s_used[seed.idx] = 1; if (dbg_order) dbg_order[c0 + seed.idx] = (atomicAdd(&dbg_order[ps.seg_path_off[ps.n_segments]], 1u) << 2); }
         __syncthreads();
         for (int dir = 1; dir <= 2; ++dir) {
             u32 cur = seed.idx;
@@ -332,6 +333,7 @@ __global__ void __launch_bounds__(64) k_guided_chain(PathSet ps, const unsigned 
                 if (nx.idx == GASM_NONE32) break;
                 if (lane == 0) {
                     s_used[nx.idx] = 1;
+                    if (dbg_order) dbg_order[c0 + nx.idx] = (atomicAdd(&dbg_order[ps.seg_path_off[ps.n_segments]], 1u) << 2) | (u32)dir;
                     if (dir == 1) { g_next[c0 + cur] = c0 + nx.idx; g_prev[c0 + nx.idx] = c0 + cur; }
                     else { g_next[c0 + nx.idx] = c0 + cur; g_prev[c0 + cur] = c0 + nx.idx; }
                 }

@@ -359,7 +359,12 @@ int guided_build(gasm_ctx* ctx, DevReads& rd, BuildState& bs, DevPaths& cp, Scor
     const size_t fx_off = (cs.stride * 4 + 15) & ~(size_t)15;
     const unsigned long long* d_fx = reinterpret_cast<const unsigned long long*>(static_cast<const char*>(cs.d_total.p) + fx_off);
     AsmLap lap;
-    GLAUNCH(ctx, "k_guided_chain", k_guided_chain, dim3(S), dim3(64), (size_t)max_c + 16, cp.view(), d_fx, k, d_next.as<u32>(), d_prev.as<u32>());
+    DBuf d_order;
+    struct RelO { DBuf* b; ~RelO() { b->release(); } } relo{&d_order};
+    const bool dbg_order = getenv("GASM_DBG_GUIDED") != nullptr;
+    if (dbg_order) { GCHK(d_order.ensure(((size_t)P + 1) * 4)); HIPCHK(hipMemsetAsync(d_order.p, 0, ((size_t)P + 1) * 4, ctx->stream)); }
+    GLAUNCH(ctx, "k_guided_chain", k_guided_chain, dim3(S), dim3(64), (size_t)max_c + 16, cp.view(), d_fx, k, d_next.as<u32>(), d_prev.as<u32>(),
+            dbg_order ? d_order.as<u32>() : (u32*)nullptr);
     std::vector<u32> next(P), prev(P);
     if (P) {
         HIPCHK(hipMemcpyAsync(next.data(), d_next.p, (size_t)P * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -367,6 +372,19 @@ int guided_build(gasm_ctx* ctx, DevReads& rd, BuildState& bs, DevPaths& cp, Scor
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     lap(ctx, "guided: chain kernel + links back");
+    if (const char* dump = getenv("GASM_DBG_GUIDED")) {        // diagnostic: the links and the sums the kernel saw
+        std::vector<unsigned long long> hfx(P);
+        if (P) HIPCHK(hipMemcpy(hfx.data(), d_fx, (size_t)P * 8, hipMemcpyDeviceToHost));
+        std::vector<u64> hoff((size_t)P + 1);
+        if (P) HIPCHK(hipMemcpy(hoff.data(), cp.view().p_off, ((size_t)P + 1) * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(dump, "wb")) {
+            std::vector<u32> hord((size_t)P + 1);      // per contig: (when it joined a path) << 2 | 0 seed, 1 right, 2 left
+            HIPCHK(hipMemcpy(hord.data(), d_order.p, hord.size() * 4, hipMemcpyDeviceToHost));
+            fwrite(&P, 4, 1, f); fwrite(next.data(), 4, P, f); fwrite(prev.data(), 4, P, f); fwrite(hfx.data(), 8, P, f); fwrite(hoff.data(), 8, (size_t)P + 1, f);
+            fwrite(hord.data(), 4, P, f);
+            fclose(f);
+        }
+    }
     // ---- chains -> scaffolds, per segment by descending length, ties by first contig (= lexicographic: contigs are sorted
     // and begin with distinct k-mers)
     std::vector<u64> clen(P);

@@ -891,6 +891,48 @@ def test_device_resident_scaffolds(qtable, monkeypatch):
         sc.close()
 
 
+def test_guided_traversal_with_large_fixed_point_sums(qtable):
+    """The guided traversal compares contig scores as exact rationals (128-bit cross products).  With few reads the batch's
+    fixed-point shift is large (>= 63) and the sums have 50+ bits: the regime in which round 2's comparator picked wrong seeds
+    (found by tools/soak.py seed 91; tests/golden/guided_case_seed91.npz keeps that segment's reads: 2-letter genome, 367
+    contigs, 358 of them tied at score 0).  The kept case plus a few dozen random small batches of the same kind."""
+    from oracle import guided_oracle
+    keys, prob = qtable
+    table = dict(zip(keys, prob.tolist()))
+
+    def check(reads, off, k, tag):
+        b = ga.SegmentBatch(reads.reshape(-1), np.array(off, dtype=np.uint64), fixed_len=reads.shape[1])
+        b.build(k).score(8, prob)
+        contigs, sc = b.contigs(), b.scores()
+        fx, shift = b.score_fixed()
+        g = b.guided()
+        for s in range(len(off) - 1):
+            rs = _strs(reads[off[s]:off[s + 1]])
+            a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
+            ofx = guided_oracle.fixed_sums(contigs[s], rs, table, 8, shift)
+            assert ofx == fx[a:e].tolist(), tag
+            assert [d["sequence"] for d in g[s]] == guided_oracle.guided_paths(contigs[s], ofx, k), (tag, s, shift)
+        b.close()
+        return shift
+
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "guided_case_seed91.npz"))
+    assert check(d["reads"], [0, d["reads"].shape[0]], int(d["k"]), "kept case") >= 63
+    rng = np.random.default_rng(4321)
+    big = 0
+    for it in range(40):
+        L, k, rl = int(rng.integers(800, 3500)), int(rng.choice([9, 21, 27])), int(rng.integers(40, 110))
+        lut = np.frombuffer(str(rng.choice(["AC", "ACGT", "CT"])).encode(), dtype=np.uint8)
+        parts, off = [], [0]
+        for s in range(int(rng.integers(1, 4))):
+            g = synth.make_segment(int(rng.integers(1 << 30)), L, planted=False)
+            g = lut[np.frombuffer(g.tobytes(), dtype=np.uint8) % len(lut)]
+            r = synth.simulate_reads(g, rl, float(rng.uniform(5, 20)), int(rng.integers(1 << 30)))
+            parts.append(r)
+            off.append(off[-1] + r.shape[0])
+        big += check(np.concatenate(parts, axis=0), off, k, it) >= 63
+    assert big >= 10
+
+
 def test_guided_traversal_against_own_restatement(qtable):
     """SURVEY §8 row A16 (configs[4]'s "combined" mode).  Not in the reference: gasm_batch_guided is checked against
     oracle/guided_oracle.py, the CPU restatement of this project's own specification — the fixed-point sums it steers by

@@ -165,7 +165,12 @@ while time.time() - t0 < budget:
             a, e = int(sc["seg_contig_off"][s]), int(sc["seg_contig_off"][s + 1])
             ofx = guided_oracle.fixed_sums(contigs[s], rs, table, 8, shift)
             assert ofx == fx[a:e].tolist(), (tag, "guided sums", s)
-            assert [d["sequence"] for d in gd[s]] == guided_oracle.guided_paths(contigs[s], ofx, k), (tag, "guided", s)
+            want = guided_oracle.guided_paths(contigs[s], ofx, k)
+            if [d["sequence"] for d in gd[s]] != want:          # keep the case for a post-mortem
+                os.makedirs("gpurun_out", exist_ok=True)
+                np.savez("gpurun_out/soak_guided_case.npz", genome=genomes[s], reads=reads[off[s]:off[s + 1]], k=k, fx=np.array(ofx, dtype=np.uint64),
+                         shift=shift, contigs=np.array(contigs[s]), got=np.array([d["sequence"] for d in gd[s]]), want=np.array(want))
+            assert [d["sequence"] for d in gd[s]] == want, (tag, "guided", s)
     b.close()
     # ragged reads (some shorter than k, some empty) through the general scorer; calc_breakscore with KS on random paths
     if rounds % 5 == 3:
