@@ -272,20 +272,28 @@ struct GBest { unsigned long long fs; u32 len; u32 idx; };
 __device__ __forceinline__ bool gbest_better(const GBest& a, const GBest& b) {          // a before b?
     if (b.idx == GASM_NONE32) return a.idx != GASM_NONE32;
     if (a.idx == GASM_NONE32) return false;
-    // a.fs / a.len > b.fs / b.len  <=>  a.fs * b.len > b.fs * a.len, in 128 bits.  (Round 2 spelled this with two __umul64hi
-    // and two 64-bit products; inside this kernel that form chose wrong seeds whenever the sums had 50+ bits — 843 of 20 338
-    // random segments of tools/soak_guided.py, none with this form; the same comparator in a kernel of its own
-    // (tools/micro/mulhi_test2.hip) is right, so the spelling is not what was wrong, the code generated for it here was.)
+    // a.fs / a.len > b.fs / b.len  <=>  a.fs * b.len > b.fs * a.len, in 128 bits
     const unsigned __int128 pa = (unsigned __int128)a.fs * b.len, pb = (unsigned __int128)b.fs * a.len;
     if (pa != pb) return pa > pb;
     return a.idx < b.idx;
+}
+// b = c if c is better — field by field with selects, NOT `if (gbest_better(c, b)) b = c;`: for that form hipcc (ROCm 7.2,
+// gfx950, -O3) generated code in k_guided_chain's candidate loop that updated b.fs and b.idx but left b.len at the length of the
+// lane's FIRST candidate (ISA: `v_mov_b32 v13, v16` on every comparing lane after `; implicit-def: $vgpr13`), so ratios were taken
+// with the wrong denominator and the traversal chose wrong seeds (found by tools/soak.py seed 91; tools/micro/guided_repro.hip is
+// the stand-alone reproducer; an emulation of exactly that defect reproduces the old kernel's output on the kept case).
+__device__ __forceinline__ void gbest_take(GBest& b, const GBest& c) {
+    const bool take = gbest_better(c, b);
+    b.fs = take ? c.fs : b.fs;
+    b.len = take ? c.len : b.len;
+    b.idx = take ? c.idx : b.idx;
 }
 __device__ __forceinline__ GBest gbest_wave(GBest v) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
         GBest o;
         o.fs = __shfl_xor(v.fs, d, 64); o.len = __shfl_xor(v.len, d, 64); o.idx = __shfl_xor(v.idx, d, 64);
-        if (gbest_better(o, v)) v = o;
+        gbest_take(v, o);
     }
     return v;
 }
@@ -317,7 +325,7 @@ __global__ void __launch_bounds__(64) k_guided_chain(PathSet ps, const unsigned 
             if (mode == 1 && !bases_eq_short(ps.words, ce - k1, jb, k1)) continue;
             if (mode == 2 && !bases_eq_short(ps.words, je - k1, cb, k1)) continue;
             const GBest c{fx[c0 + j], (u32)(je - jb), j};
-            if (gbest_better(c, b)) b = c;
+            gbest_take(b, c);
         }
         return gbest_wave(b);
     };

@@ -892,10 +892,11 @@ def test_device_resident_scaffolds(qtable, monkeypatch):
 
 
 def test_guided_traversal_with_large_fixed_point_sums(qtable):
-    """The guided traversal compares contig scores as exact rationals (128-bit cross products).  With few reads the batch's
-    fixed-point shift is large (>= 63) and the sums have 50+ bits: the regime in which round 2's comparator picked wrong seeds
-    (found by tools/soak.py seed 91; tests/golden/guided_case_seed91.npz keeps that segment's reads: 2-letter genome, 367
-    contigs, 358 of them tied at score 0).  The kept case plus a few dozen random small batches of the same kind."""
+    """The guided traversal compares contig scores as exact rationals (128-bit cross products).  Round 2's kernel chose wrong
+    seeds on small, tie-rich segments: the code generated for `if (better(c, b)) b = c;` left b.len at the lane's first
+    candidate's length (NOTES_r3.md; found by tools/soak.py seed 91; tests/golden/guided_case_seed91.npz keeps that segment's
+    reads: 2-letter genome, 367 contigs, 358 of them tied at score 0).  The kept case plus a few dozen random small batches of
+    the same kind (few reads: fixed-point shift >= 63, sums of 50+ bits)."""
     from oracle import guided_oracle
     keys, prob = qtable
     table = dict(zip(keys, prob.tolist()))
