@@ -378,19 +378,19 @@ def main():
     if world > 1 and args.mode == "segments" and not args.no_pooled and not one_gpu:
         psteps = max(1, min(5, args.steps))
         # watchdog thread (a signal handler would not run while the main thread sits in a blocking runtime call): after
-        # 300 s rank 0 prints the line without the pooled figures and every rank leaves with status 3
+        # 180 s rank 0 prints the line without the pooled figures and every rank leaves with status 3
         import threading
         pending = {"comm": None}
 
         def give_up():
             st = pending["comm"].stage() if pending["comm"] is not None else -1
-            print(f"[bench] rank {rank}: the pooled steps did not finish within 300 s (libgasm exchange stage {st}: 10 local runs, 11-13 exchange 1, "
+            print(f"[bench] rank {rank}: the pooled steps did not finish within 180 s (libgasm exchange stage {st}: 10 local runs, 11-13 exchange 1, "
                   "21-23 exchange 2, 31 reads, 32 scoring, -1 set-up)", file=sys.stderr, flush=True)
             if rank == 0:
                 _print_line(args, world, nseg, L, rl, cov, k, n_kmers, n_reads, n_distinct, dt, roofline, None, breakdown,
-                            {"error": f"the pooled steps did not finish within 300 s (rank 0 at exchange stage {st})"}, None, pcie, guided_info)
+                            {"error": f"the pooled steps did not finish within 180 s (rank 0 at exchange stage {st})"}, None, pcie, guided_info)
             os._exit(3)
-        dog = threading.Timer(300.0, give_up)
+        dog = threading.Timer(180.0, give_up)
         dog.daemon = True
         dog.start()
         try:
