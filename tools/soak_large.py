@@ -21,11 +21,15 @@ t0, rounds, checked = time.time(), 0, 0
 while time.time() - t0 < budget:
     S = int(rng.integers(20, 130))
     L = int(rng.integers(8000, 50001))
+    if os.environ.get("SOAK_MANY_SEGMENTS") and rounds % 2 == 0:      # more segments than CUs: the other side of several launch decisions
+        S = int(rng.integers(260, 1300))
+        L = int(rng.integers(600, 6000))
     k = int(rng.choice([15, 21, 31, 33, 51, 63]))
     rl = int(rng.integers(max(k + 10, 60), 260))
     cov = float(rng.uniform(8, 45))
     while S * L * cov / rl * (rl - k + 1) > 3.5e8:        # keep a batch near the bench's size
         S = max(8, S // 2)
+    rl = min(rl, max(k + 2, L // 3))
     hint = int(rng.choice([0, L]))
     reads, seg_off, genomes = synth.make_batch(S, L, rl, cov, seed0=int(rng.integers(1 << 30)), planted=bool(rng.integers(0, 2)))
     tag = f"S={S} L={L} k={k} rl={rl} cov={cov:.1f} hint={hint} reads={reads.shape[0]}"
