@@ -671,6 +671,22 @@ def _check_batch_properties(b, seg_off, rl, k, n_seg):
     return contigs, sc
 
 
+def test_more_segments_than_cus(qtable):
+    """A batch with more segments than the chip has CUs (configs[3] on fewer GPUs than eight looks like this): the other side
+    of several launch decisions — the LDS list of the ranking sized by the estimate, rulers at every second edge, more than
+    one round of the segment-major grids and of the 64-segment directory scan.  Properties on all 600 segments, the oracle on a
+    sample; two steps in flight on the way."""
+    keys, prob = qtable
+    n_seg, L, rl, cov, k = 600, 900, 50, 22, 21
+    reads, seg_off, genomes = synth.make_batch(n_seg, L, rl, cov, seed0=6100, planted=False)
+    b = ga.SegmentBatch(reads.reshape(-1), seg_off, fixed_len=rl)
+    b.build(k, genome_len_hint=L).score(8, prob)
+    b.build(k, genome_len_hint=L).score(8, prob)
+    contigs, sc = _check_batch_properties(b, seg_off, rl, k, n_seg)
+    _check_segments_vs_oracle(b, reads, seg_off, genomes, [0, 1, 63, 64, 255, 256, 257, 511, 512, 598, 599], k, keys, prob, contigs, sc)
+    b.close()
+
+
 @pytest.mark.parametrize("n_seg,L,rl,cov,k", [(20, 3000, 60, 25, 21), (80, 1500, 40, 30, 15), (70, 1200, 90, 20, 33)])
 def test_many_segments_against_oracle(qtable, n_seg, L, rl, cov, k):
     """more than 8 and more than 64 segments, all against the oracle: the segment-major grids (seg_chunk), the 64-segment
