@@ -160,11 +160,6 @@ static int batch_finish(gasm_batch* b) {
         return GASM_ERR_INVALID;                                               \
     }
 
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
-static bool env_flag(const char* name, bool dflt) {
-    const char* v = getenv(name);
-    return v && *v ? *v != '0' : dflt;
-}
 static bool score_lane_wanted(const gasm_batch* b) {
     const char* v = getenv("GASM_SCORE_LANE");
     return b->sub.size() == 1 && !(v && *v == '0');

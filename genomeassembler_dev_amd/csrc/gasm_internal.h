@@ -128,6 +128,10 @@ struct gasm_ctx {
         HIPCHK(hipGetLastError());                                                           \
     } while (0)
 
+// environment knobs (diagnostics and the documented switches): an integer / a flag ("0" = off), with a default
+static inline int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
+static inline bool env_flag(const char* name, bool dflt) { const char* v = getenv(name); return v && *v ? *v != '0' : dflt; }
+
 static inline u32 ceil_div_u64(u64 a, u64 b) { return (u32)((a + b - 1) / b); }
 static inline u32 next_pow2_u32(u32 x) {
     u32 p = 1;

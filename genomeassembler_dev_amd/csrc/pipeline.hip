@@ -56,7 +56,6 @@ static const Knobs& knobs() { static const Knobs k; return k; }
 // knobs read at every build (tests switch them inside one process):
 //   GASM_SINGLE_PASS=0     two-pass partition (count, scan, scatter) from the start       GASM_PART_SLACK=percent   room per bucket region (100)
 //   GASM_DBG_PART_CAP=n    force the capacity of every bucket region to n keys (exercises the overflow path)
-static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; }
 
 // Wait for a report a kernel writes into pinned host memory: the kernel's last store is `ticket` at `word`.  Spinning on
 // that word costs a few microseconds; waking up from hipStreamSynchronize costs 15-20 us (more on a busy host) — twice

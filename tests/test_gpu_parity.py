@@ -417,12 +417,15 @@ def test_levenshtein_kernel_against_oracle(qtable):
     reads = [truth[i:i + 40] for i in range(0, 5900, 50)]
     os.environ["GASM_LEV_GPU"] = "1"          # (a dozen paths would go to the host routine otherwise: see gasm_calc_breakscore)
     try:
-        for variant in ("own", "velvet"):
-            m = ga.calc_breakscore(paths, reads, truth, 8, keys, prob, variant=variant, with_lev=True, with_freq=False)
-            ref = [orc.levenshtein(p, truth, infix=(variant == "velvet")) for p in paths]
-            assert m["lev_dist_vs_true"].tolist() == ref, variant
+        for version in ("2", "1"):            # k_levenshtein2 (the default) and the first form of the kernel (GASM_LEV_V=1)
+            os.environ["GASM_LEV_V"] = version
+            for variant in ("own", "velvet"):
+                m = ga.calc_breakscore(paths, reads, truth, 8, keys, prob, variant=variant, with_lev=True, with_freq=False)
+                ref = [orc.levenshtein(p, truth, infix=(variant == "velvet")) for p in paths]
+                assert m["lev_dist_vs_true"].tolist() == ref, (variant, version)
     finally:
         del os.environ["GASM_LEV_GPU"]
+        os.environ.pop("GASM_LEV_V", None)
     # a target with a byte outside ACGT goes through the host routine
     t2 = truth[:500] + "N" + truth[500:900]
     m = ga.calc_breakscore(paths[2:6], reads, t2, 8, keys, prob, variant="own", with_lev=True, with_freq=False)
