@@ -674,6 +674,32 @@ def _check_batch_properties(b, seg_off, rl, k, n_seg):
     return contigs, sc
 
 
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    """bench.py on the smallest workload: file descriptor 1 carries exactly ONE line, a JSON object with the keys of the
+    contract (metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling / vs_baseline /
+    dtype / data / config.workload) plus `roofline` (bound, achieved, peak, unit, frac, traffic; the kernel's own duration and the
+    timed region's residence times) — whatever libraries print on the way (RCCL and Gloo banners) goes to stderr."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "cfg1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [x for x in p.stdout.split("\n") if x.strip()]
+    assert len(lines) == 1, p.stdout[:500]
+    j = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["n_gpus"] == 1 and j["steps"] == 6 and j["warmup"] == 2 and j["higher_is_better"] is True and j["data"] == "synthetic"
+    assert "workload" in j["config"] and j["value"] > 0 and abs(j["value"] - j["config"]["kmers_per_step"] / (j["ms_per_step"] * 1e-3)) < 1e-3 * j["value"]
+    r = j["roofline"]
+    for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "measured", "timed_region", "step"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
 def test_more_segments_than_cus(qtable):
     """A batch with more segments than the chip has CUs (configs[3] on fewer GPUs than eight looks like this): the other side
     of several launch decisions — the LDS list of the ranking sized by the estimate, rulers at every second edge, more than
